@@ -1,0 +1,128 @@
+"""CPU: the oracle restatement (oracle/seedstory_oracle.py) against the golden vectors that
+oracle/make_golden.py produced by running the REAL reference modules."""
+import torch
+
+import seedstory_oracle as O
+import synth
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+def _llama(meta, dtype):
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    return wd, dims
+
+
+def _img_ids(meta):
+    lo, hi = meta["IMG_IDS"]
+    return list(range(lo, hi + 1))
+
+
+def test_llama_prefill_continuation_decode_fp32(golden):
+    g, meta = golden
+    wd, dims = _llama(meta, torch.float32)
+    emb = wd["model.embed_tokens.weight"]
+    lg, hid, kv = O.llama_forward(wd, dims, emb[g["llama_f32.ids"]], torch.arange(37).unsqueeze(0))
+    assert rel(lg, g["llama_f32.prefill_logits"]) < 2e-6
+    assert rel(hid, g["llama_f32.prefill_hidden"]) < 2e-6
+    assert rel(kv[0][0], g["llama_f32.prefill_k0"]) < 2e-6
+    assert rel(kv[1][1], g["llama_f32.prefill_v1"]) < 2e-6
+    lg2, hid2, kv2 = O.llama_forward(wd, dims, emb[g["llama_f32.ids2"]], torch.arange(37, 46).unsqueeze(0), kv)
+    assert rel(lg2, g["llama_f32.cont_logits"]) < 2e-6
+    lg3, hid3, _ = O.llama_forward(wd, dims, emb[g["llama_f32.ids3"]], torch.tensor([[46]]), kv2)
+    assert rel(lg3, g["llama_f32.decode_logits"]) < 2e-6
+    assert rel(hid3, g["llama_f32.decode_hidden"]) < 2e-6
+
+
+def test_llama_bf16_rounding_points(golden):
+    g, meta = golden
+    wd, dims = _llama(meta, torch.bfloat16)
+    emb = wd["model.embed_tokens.weight"]
+    lg, hid, kv = O.llama_forward(wd, dims, emb[g["llama_bf16.ids"]], torch.arange(37).unsqueeze(0))
+    # same ops in the same order as the reference's bf16 CPU path
+    assert rel(lg, g["llama_bf16.prefill_logits"]) < 1e-2
+    assert rel(kv[0][0], g["llama_bf16.prefill_k0"]) < 1e-2
+    x = g["llama_bf16.rmsnorm_in"].bfloat16()
+    y = O.rmsnorm(x, wd["model.layers.0.input_layernorm.weight"], 1e-5)
+    assert torch.equal(y.float(), g["llama_bf16.rmsnorm_out"])
+    q = g["llama_bf16.rope_in"].bfloat16()
+    c, s = O.rope_tables(128, 4096, torch.bfloat16)
+    assert torch.equal(O.apply_rope(q, c, s, torch.tensor([[3, 9, 10, 40, 63]])).float(), g["llama_bf16.rope_out"])
+
+
+def test_rmsnorm_rope_fp32_exact(golden):
+    g, meta = golden
+    wd, dims = _llama(meta, torch.float32)
+    y = O.rmsnorm(g["llama_f32.rmsnorm_in"], wd["model.layers.0.input_layernorm.weight"], 1e-5)
+    assert rel(y, g["llama_f32.rmsnorm_out"]) < 1e-6
+    c, s = O.rope_tables(128, 4096, torch.float32)
+    r = O.apply_rope(g["llama_f32.rope_in"], c, s, torch.tensor([[3, 9, 10, 40, 63]]))
+    assert rel(r, g["llama_f32.rope_out"]) < 1e-6
+
+
+def test_logits_processor(golden):
+    g, meta = golden
+    ids = _img_ids(meta)
+    for i, last in enumerate(g["proc.last_ids"].tolist()):
+        sc = synth.normal_like(300 + i, (1, meta["LLAMA"]["vocab"]), 2.0)[0]
+        out = O.image_token_logits_processor(last, sc.clone(), ids)
+        assert torch.equal(out, g["proc.out"][i])
+
+
+def test_resamplers(golden):
+    g, meta = golden
+    for tag, key, seed in (("res_in", "RES_IN", 21), ("res_out", "RES_OUT", 22)):
+        c = meta[key]
+        wd = synth.resampler_weights(seed, "", c["grid"], c["embed"])
+        y = O.resampler_forward(wd, "", g[tag + ".x"], c["heads"])
+        assert rel(y, g[tag + ".y"]) < 2e-6
+
+
+def test_vit(golden):
+    g, meta = golden
+    c = meta["VIT"]
+    wd = synth.vit_weights(31, c["width"], c["layers"], c["heads"], c["mlp_width"], c["patch"], c["out_dim"],
+                           c["n_queries"])
+    y = O.vit_forward(wd, g["vit.x"], width=c["width"], layers=c["layers"], heads=c["heads"], patch=c["patch"],
+                      out_dim=c["out_dim"], n_queries=c["n_queries"])
+    assert rel(y, g["vit.y"]) < 2e-6
+
+
+def test_resampler_xlv2(golden):
+    g, meta = golden
+    c = meta["XLV2"]
+    wd = synth.resampler_xlv2_weights(41, **c)
+    ctx, pooled = O.resampler_xlv2_forward(wd, g["xlv2.x"], depth=c["depth"], heads=c["heads"],
+                                           dim_head=c["dim_head"])
+    assert rel(ctx, g["xlv2.ctx"]) < 2e-6
+    assert rel(pooled, g["xlv2.pooled"]) < 2e-6
+
+
+def test_lvlm_generate(golden):
+    g, meta = golden
+    wd, dims = _llama(meta, torch.float32)
+    wd.update(synth.resampler_weights(21, "input_resampler.", meta["RES_IN"]["grid"], 256))
+    wd.update(synth.resampler_weights(22, "output_resampler.", meta["RES_OUT"]["grid"], 256))
+    input_ids = g["gen.input_ids"]
+    n_in = meta["RES_IN"]["grid"] ** 2
+    mask = torch.zeros_like(input_ids, dtype=torch.bool)
+    mask[0, 14:14 + n_in] = True
+    out = O.lvlm_generate(wd, dims, input_ids, g["gen.image_embeds"], torch.tensor([True]), mask, _img_ids(meta),
+                          max_new_tokens=90, forced=g["gen.forced"].tolist(), n_heads_resampler=2)
+    assert out["generate_ids"] == g["gen.generate_ids"].tolist()
+    assert rel(out["hidden"], g["gen.hidden"]) < 2e-6
+    assert rel(out["img_gen_feat"], g["gen.img_gen_feat"]) < 2e-6
+
+
+def test_lora_linear_equals_merged():
+    x = synth.normal_like(1, (3, 64), 1.0)
+    w = synth.normal_like(2, (32, 64))
+    a = synth.normal_like(3, (16, 64))
+    b = synth.normal_like(4, (32, 16))
+    y = O.lora_linear(x, w, a, b, 2.0)
+    ym = torch.nn.functional.linear(x, O.lora_merge(w, a, b, 2.0))
+    assert rel(ym, y) < 1e-6
