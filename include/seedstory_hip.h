@@ -1,0 +1,285 @@
+/* libseedstory_hip.so — C ABI of the MI355X-native (gfx950) SEED-Story hot path.
+ *
+ * The reference (TencentARC/SEED-Story) has no FFI: its hot path sits behind Python-level
+ * plug points.  This header is the boundary a maintainer binds with
+ * ctypes from those plug points; every entry point cites the
+ * reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Rules of the ABI
+ *   - plain pointers and sizes only; pointers are DEVICE pointers unless named host_*;
+ *   - every call enqueues asynchronously on the caller's `stream` (a hipStream_t passed
+ *     as void*; NULL = the legacy default stream) and returns immediately;
+ *   - return 0 (SS_OK) or a negative SS_E* code; ss_last_error() gives the message
+ *     (thread-local); nothing throws; nothing allocates or frees caller memory —
+ *     workspaces are passed in, sized by the *_workspace_bytes() queries; the only
+ *     library-owned objects are the engine handles (ss_llama_create / ss_vit_create …);
+ *   - `dtype` is the model dtype of activations AND weights: SS_F32 (CPU-parity mode),
+ *     SS_BF16 (production), SS_F16.  Accumulation is always fp32; values are rounded to
+ *     the model dtype where the reference's torch graph rounds them.
+ *   - there is no CPU fallback: every function fails with SS_EHIP when no gfx950 device
+ *     is usable.
+ */
+#ifndef SEEDSTORY_HIP_H_
+#define SEEDSTORY_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+enum { SS_F32 = 0, SS_BF16 = 1, SS_F16 = 2 };
+enum { SS_OK = 0, SS_EINVAL = -1, SS_EHIP = -2, SS_ENOMEM = -3, SS_ESTATE = -4 };
+
+/* GEMM / GEMV epilogues (bit flags) */
+enum {
+    SS_EPI_NONE = 0,
+    SS_EPI_BIAS = 1,      /* + bias[N]                                                   */
+    SS_EPI_GELU = 2,      /* exact-erf GELU after bias (nn.GELU, qwen_visual.py:258-260)  */
+    SS_EPI_RESIDUAL = 4,  /* out = residual + round_T(acc [+bias])                        */
+    SS_EPI_SILU_MUL = 8   /* GEMV only: y[n] = silu(acc[n]) * acc[n+N]  (LlamaMLP :190)   */
+};
+
+const char* ss_last_error(void);
+int ss_abi_version(void);
+/* Device properties of the current HIP device: out[0]=CU count, out[1]=is_gfx950,
+ * out[2]=total HBM MiB, out[3]=wavefront size. */
+int ss_device_info(int32_t out[4]);
+/* Runtime tuning knobs (grid sizes, rows per wave, …); unknown keys are accepted. */
+int ss_set_tuning(const char* key, int value);
+int ss_get_tuning(const char* key, int dflt);
+
+/* ---------------------------------------------------------------------------------------
+ * Norms and element-wise ops
+ * ------------------------------------------------------------------------------------- */
+
+/* LlamaRMSNorm.forward — src/models_clm/modeling_llama_xformer.py:107-115.
+ * y = w * round_T(x * rsqrt(mean_fp32(x^2) + eps)); x,y [rows, cols]; w [cols]. */
+int ss_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t cols, float eps, int dtype,
+               void* stream);
+
+/* nn.LayerNorm (qwen_visual.py:103,353; resampler.py norm layers): fp32 statistics,
+ * y = round_T((x-mean)*rstd*w + b). */
+int ss_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, float eps,
+                 int dtype, void* stream);
+
+/* y[b, r, :] = x[b, r, :] + p[r, :]   (position-embedding adds, qwen_visual.py:147-148,387;
+ * x may be NULL-batched: if x_batch_stride == 0 the same x rows are used for every b). */
+int ss_add_bcast(const void* x, const void* p, void* y, int64_t batch, int64_t rows, int64_t cols,
+                 int64_t x_batch_stride, int dtype, void* stream);
+
+/* out[r, i] = silu(gu[r, i]) * gu[r, inter + i]; gu [rows, 2*inter] (LlamaMLP, :190-191). */
+int ss_silu_mul(const void* gu, void* out, int64_t rows, int64_t inter, int dtype, void* stream);
+
+/* Embedding lookup: out[i, :] = table[ids[i], :] (models.py:127); ids int32 on device. */
+int ss_gather_rows(const void* table, const int32_t* ids, void* out, int64_t n, int64_t cols, int dtype,
+                   void* stream);
+/* Splice: dst[idx[i], :] = src[i, :] (models.py:135: input_embeds[ids_cmp_mask] = ...). */
+int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t cols, int dtype,
+                    void* stream);
+/* Conv2d(k=stride=patch, no bias) input re-layout for the ViT patch embed (qwen_visual.py:347,382):
+ * img [B,3,S,S] (T) -> patches [B*(S/p)^2, kpad] with column order (c, dy, dx), zero padded to kpad. */
+int ss_im2col_patch(const void* img, void* out, int64_t batch, int64_t size, int64_t patch, int64_t kpad,
+                    int dtype, void* stream);
+/* F.normalize(x) over dim=1 of [B, L, C] (resampler.py:269): x / max(||x||_2 over L, 1e-12). */
+int ss_l2normalize_dim1(const void* x, void* y, int64_t batch, int64_t len, int64_t cols, int dtype,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RoPE + KV cache
+ * ------------------------------------------------------------------------------------- */
+
+/* apply_rotary_pos_emb + KV concatenation — modeling_llama_xformer.py:158-173, 236-242.
+ * qkv [M, 3*n_heads*hd] (q | k | v per token).  Rotates q in the model dtype with the
+ * (model-dtype) tables cos/sin [max_pos, hd] at positions pos_ids[m] (device int32; if NULL,
+ * pos_start + m), writes q_out [M, n_heads*hd], and appends rotated k and v into the caches
+ * kcache/vcache [n_heads, cache_cap, hd] at slots kv_start + m (keys cached AFTER RoPE). */
+int ss_rope_kv_append(const void* qkv, void* q_out, void* kcache, void* vcache, const void* cos,
+                      const void* sin, const int32_t* pos_ids, int64_t pos_start, int64_t M, int64_t n_heads,
+                      int64_t hd, int64_t kv_start, int64_t cache_cap, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Attention
+ * ------------------------------------------------------------------------------------- */
+
+/* Fused softmax attention (flash style, MFMA) replacing
+ *   xops.memory_efficient_attention(q,k,v, LowerTriangularFromBottomRightMask) (:289-295)
+ *   when causal_br=1 (query i attends keys j <= i + kv_len - q_len), and the unfused
+ *   bmm/softmax/bmm of VisualAttention (qwen_visual.py:207-220), nn.MultiheadAttention
+ *   (:147-149) and PerceiverAttention (resampler.py:69-72) when causal_br=0.
+ * Element (b,h,i,d) of q is at q + b*q_sb + h*q_sh + i*q_ss + d (strides in elements),
+ * likewise k/v (k_s*, v_s*) and out (o_s*).  hd <= 128 (104 and 64 are supported);
+ * softmax in fp32; P and output rounded to T.  `scale` multiplies q·k. */
+int ss_attention(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t n_heads,
+                 int64_t q_len, int64_t kv_len, int64_t hd, int64_t q_sb, int64_t q_sh, int64_t q_ss,
+                 int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                 int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, int causal_br, int dtype,
+                 void* stream);
+
+/* Single-query decode attention over the KV cache (q_len = 1 case of :289-295), split-KV.
+ * q [n_heads*hd]; caches [n_heads, cache_cap, hd]; kv_len read on the device from
+ * *kv_len_dev (so the launch can be replayed from a hipGraph); out [n_heads*hd].
+ * workspace: ss_attn_decode_workspace_bytes(n_heads, hd). */
+size_t ss_attn_decode_workspace_bytes(int64_t n_heads, int64_t hd);
+int ss_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, void* workspace,
+                   const int32_t* kv_len_dev, int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense contractions
+ * ------------------------------------------------------------------------------------- */
+
+/* C[M,N] = A[M,K] · W[N,K]^T (+bias) (+GELU) (+residual)   — nn.Linear everywhere on the path
+ * (modeling_llama_xformer.py:228-230,297,191; qwen_visual.py:191,259; resampler.py).
+ * MFMA (bf16/f16: 16x16x32, f32: 16x16x4); lda/ldw/ldc/ldr in elements; K % 8 == 0. */
+int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+            int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, int dtype,
+            void* stream);
+
+/* y[N] = W[N,K] · x[K] — the batch-1 decode projection (weight streaming, HBM-bound).
+ * Optional fused prologue: if norm_w != NULL, x is first RMS-normalised (as ss_rmsnorm).
+ * Epilogues: SS_EPI_RESIDUAL (y = residual + round_T(acc)), SS_EPI_SILU_MUL (W is
+ * [2N, K] = [gate; up], y[n] = silu(gate·x) * (up·x)), SS_EPI_BIAS.  K % 8 == 0. */
+int ss_gemv(const void* W, const void* x, void* y, int64_t N, int64_t K, const void* norm_w, float eps,
+            const void* bias, const void* residual, int epilogue, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sampling: lm_head logits -> AutoImageTokenGenerationProcessor -> greedy argmax
+ * ------------------------------------------------------------------------------------- */
+
+/* src/models_clm/generation.py:19-31 + HF greedy argmax, on device:
+ * logits [vocab] (T, modified in place like the reference does), last_id = *last_id_dev,
+ * img_ids int32[n_img_ids] = ids of <img><img_00000>…</img>.  If last_id is one of
+ * img_ids[:-1] the successor's score becomes max+10, else scores[img_ids[1:]] = 0.0;
+ * then the first maximal index is written to *token_out_dev. */
+int ss_imgproc_argmax(void* logits, int64_t vocab, const int32_t* last_id_dev, const int32_t* img_ids,
+                      int64_t n_img_ids, int32_t* token_out_dev, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LLaMA decoder engine (native runtime: KV cache, prefill loop, hipGraph-captured decode)
+ * ------------------------------------------------------------------------------------- */
+
+typedef struct ss_llama ss_llama;
+
+typedef struct ss_llama_config {
+    int32_t hidden, n_heads, n_layers, inter, vocab, max_pos; /* LlamaConfig */
+    float rms_eps;
+    int32_t dtype;
+    int32_t cache_cap;   /* KV slots per head */
+    int32_t max_new;     /* capacity of the generated-token / hidden-state ring */
+    int32_t n_img_ids;   /* 66 for SEED-Story */
+    int32_t eos_id;
+} ss_llama_config;
+
+/* Per-layer weights, all [out, in] row-major in the model dtype, LoRA already merged
+ * (or absent): wqkv [3*hidden, hidden] = [q;k;v], wo [hidden, hidden],
+ * wgu [2*inter, hidden] = [gate; up], wdown [hidden, inter], ln1, ln2 [hidden]. */
+typedef struct ss_llama_layer_weights {
+    const void *wqkv, *wo, *wgu, *wdown, *ln1, *ln2;
+} ss_llama_layer_weights;
+
+typedef struct ss_llama_weights {
+    const void* embed;    /* [vocab, hidden] */
+    const void* lm_head;  /* [vocab, hidden] */
+    const void* final_norm;
+    const void* rope_cos; /* [max_pos, hd] model dtype (LlamaRotaryEmbedding, :118-134) */
+    const void* rope_sin;
+    const ss_llama_layer_weights* layers; /* host array[n_layers] */
+} ss_llama_weights;
+
+/* Bytes of device memory the engine needs (KV cache + activations); the caller allocates it
+ * (torch) and hands it over in ss_llama_create — the engine never calls hipMalloc for it. */
+size_t ss_llama_workspace_bytes(const ss_llama_config* cfg, int64_t max_prefill_rows);
+int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void* workspace,
+                    size_t workspace_bytes, int64_t max_prefill_rows, const int32_t* host_img_ids,
+                    ss_llama** out);
+void ss_llama_destroy(ss_llama* h);
+
+/* Device pointers into the engine's workspace (views for the Python side):
+ * which: 0 = K cache [n_layers, n_heads, cache_cap, hd], 1 = V cache (same shape),
+ * 2 = generated ids int32[max_new], 3 = hidden rows [max_new, hidden] (post final norm,
+ * row j = state whose input token was generated id j; models.py:182-184),
+ * 4 = last-token logits [vocab], 5 = state int32[8] {kv_len,pos,n_gen,done,last_id,…}. */
+void* ss_llama_buffer(ss_llama* h, int which);
+
+/* Set / get the live KV length and next rope position (host view).  Truncating the cache
+ * (vis_george_sink.py:243) is ss_llama_set_lengths(h, new_len, new_pos). */
+int ss_llama_set_lengths(ss_llama* h, int64_t kv_len, int64_t pos, void* stream);
+int ss_llama_get_lengths(ss_llama* h, int64_t* kv_len, int64_t* pos);
+/* KV re-pack for the multimodal attention sink (vis_george_sink.py:266-295): new cache =
+ * old cache gathered at keep_idx[0..n_keep) (device int32, ascending), kv_len = n_keep. */
+int ss_llama_kv_gather(ss_llama* h, const int32_t* keep_idx_dev, int64_t n_keep, void* stream);
+
+/* LlamaModel.forward on M new rows against the cached prefix (prefill when the cache is
+ * empty, bottom-right-causal continuation otherwise) — modeling_llama_xformer.py:532-666.
+ * embeds [M, hidden]; pos_ids device int32[M] or NULL (pos, pos+1, …).  Writes the
+ * post-final-norm hidden rows to hidden_out [M, hidden] if non-NULL, and the LAST row's
+ * lm_head logits into the engine's logits buffer (the reference computes all rows, :759,
+ * but only row -1 is consumed by greedy search).  Advances kv_len/pos by M. */
+int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* pos_ids, void* hidden_out,
+                     void* stream);
+
+/* Greedy decode (HF greedy search as driven from models.py:146-153):
+ * starting from the logits buffer left by prefill, runs up to n_steps iterations of
+ * {processor -> argmax (or forced[i] while i < n_forced) -> append -> embed -> 32 layers ->
+ * final norm -> lm_head}, entirely on device from a captured hipGraph, stopping at EOS.
+ * last_prompt_id seeds the processor's "last token" for the first step.
+ * host_n_generated receives the number of tokens produced (synchronises the stream). */
+int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, const int32_t* host_forced,
+                      int64_t n_forced, int64_t* host_n_generated, void* stream);
+
+/* Per-kernel-class device time of one decode token, measured with hipEvents around every
+ * launch of an un-captured (eager) decode step, averaged over n_tokens:
+ * out_ms[0]=gemv total, [1]=attention(+combine), [2]=rope/kv, [3]=norm+sampling+misc,
+ * [4]=whole token; out_bytes[0] = weight bytes streamed by the GEMV launches of one token. */
+int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], double out_bytes[2],
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Learnable-query cross-attention Resampler (qwen_visual.py:95-153) — input_resampler,
+ * output_resampler ("image-feature regressor") and the ViT attn_pool.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ss_resampler_weights {
+    const void* q_in;      /* [nq, E]  = ln_q(query) + pos_embed, precomputed once at load      */
+    const void* pos_kv;    /* [Lkv, E] = get_abs_pos(pos_embed, Lkv) (bicubic, :23-39)           */
+    const void* kv_proj;   /* [E, kv_dim] or NULL (Identity when kv_dim == E, :116-121)          */
+    const void *ln_kv_w, *ln_kv_b;
+    const void *in_w, *in_b;   /* nn.MultiheadAttention in_proj [3E, E], [3E] ([Q;K;V] blocks) */
+    const void *out_w, *out_b; /* out_proj [E, E], [E]                                          */
+    int32_t nq, embed, n_heads, kv_dim, l_kv;
+    float ln_eps;
+} ss_resampler_weights;
+size_t ss_resampler_workspace_bytes(const ss_resampler_weights* w, int64_t batch, int dtype);
+/* x [batch, l_kv, kv_dim] -> y [batch, nq, E] */
+int ss_resampler_forward(const ss_resampler_weights* w, const void* x, void* y, int64_t batch, void* workspace,
+                         size_t workspace_bytes, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Qwen ViT-G trunk (qwen_visual.py:376-392: conv1 -> +pos -> ln_pre -> 48 blocks)
+ * ------------------------------------------------------------------------------------- */
+typedef struct ss_vit_layer_weights {
+    const void *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const void *in_w, *in_b;   /* attn.in_proj [3*width, width], head-interleaved [h][q|k|v] (:192-199) */
+    const void *out_w, *out_b;
+    const void *fc_w, *fc_b, *proj_w, *proj_b;
+} ss_vit_layer_weights;
+typedef struct ss_vit_weights {
+    const void* conv_w;   /* [width, kpad]  (conv1.weight flattened (c,dy,dx), zero padded to kpad) */
+    const void* pos;      /* [tokens, width] = get_abs_pos(positional_embedding, tokens)           */
+    const void *ln_pre_w, *ln_pre_b;
+    const ss_vit_layer_weights* layers; /* host array[n_layers] */
+    int32_t width, n_layers, n_heads, mlp_width, patch, image, kpad;
+    float ln_eps;
+} ss_vit_weights;
+size_t ss_vit_workspace_bytes(const ss_vit_weights* w, int64_t batch, int dtype);
+/* img [batch,3,image,image] (T) -> tokens [batch, (image/patch)^2, width] */
+int ss_vit_forward(const ss_vit_weights* w, const void* img, void* out, int64_t batch, void* workspace,
+                   size_t workspace_bytes, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDSTORY_HIP_H_ */

@@ -1,0 +1,398 @@
+// Attention kernels of the SEED-Story hot path.
+//
+//  (1) flash_attn_kernel — fused QK^T -> online softmax -> PV on the matrix cores, replacing
+//      xops.memory_efficient_attention(q, k, v, LowerTriangularFromBottomRightMask)
+//      (src/models_clm/modeling_llama_xformer.py:289-295; query i sees keys j <= i + kv - q),
+//      the materialised bmm/softmax/bmm of the ViT (src/models/qwen_visual.py:207-220,
+//      head_dim 104), nn.MultiheadAttention in the Resamplers (:147-149) and
+//      PerceiverAttention (src/models_ipa/resampler.py:69-72).
+//      Layout trick: compute S^T = K·Q^T so that a lane owns 16 scores of ONE query
+//      (q = lane & 15): the row max/sum are 15 in-lane ops + 2 shuffles, and the
+//      probabilities are already the B-fragment of O^T = V^T·P^T — P never moves between
+//      lanes; O^T's accumulator layout gives each lane 4 consecutive d of its query.
+//  (2) attn_decode_kernel + attn_combine_kernel — q_len = 1 split-KV decode attention over the
+//      KV cache (HBM-bound: streams K and V of one head once), lengths read on the device so
+//      the launch replays from a hipGraph.
+#include "ss_common.h"
+
+namespace ss {
+
+// --------------------------------------------------------------------------------------------
+// (1) flash attention
+// --------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const void *q, *k, *v;
+    void* out;
+    int q_len, kv_len, hd, n_heads;
+    int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_sh, o_ss;
+    float scale;
+    int causal_br;
+};
+
+template <typename T> struct AttnMma;
+template <> struct AttnMma<bf16_t> {
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct AttnMma<f16_t> {
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+constexpr int kBQ = 64;   // query rows per block (4 waves x 16)
+constexpr int kBKV = 64;  // keys per tile
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int KS = HD + V;    // K tile row stride (elements), padded
+    constexpr int VS = kBKV + V;  // V^T tile row stride
+    constexpr int NDB = HD / 16;  // 16-wide d blocks of the output
+    constexpr int NKB = kBKV / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);  // [kBKV][KS]
+    T* Vt = Ks + kBKV * KS;                  // [HD][VS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.n_heads, h = bh % a.n_heads;
+    const int q0 = blockIdx.x * kBQ;
+    const int qi = q0 + wid * 16 + l15;  // this lane's query row
+    const int hd = a.hd;
+    const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+    const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int shift = a.kv_len - a.q_len;  // bottom-right alignment
+
+    // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel ----------------
+    // bf16/f16: qf[ks] = Q[qi][ks*32 + grp*8 .. +8];  f32: qs[kk] = Q[qi][kk*4 + grp]
+    uint4 qf[V == 8 ? HD / 32 : 1];
+    float qs[V == 4 ? HD / 4 : 1];
+    if constexpr (V == 8) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            const int d = ks * 32 + grp * 8;
+            qf[ks] = (qi < a.q_len && d < hd) ? ld16(qp + (int64_t)qi * a.q_ss + d) : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < HD / 4; ++kk) {
+            const int d = kk * 4 + grp;
+            qs[kk] = (qi < a.q_len && d < hd) ? Tr<T>::ld(qp + (int64_t)qi * a.q_ss + d) : 0.f;
+        }
+    }
+
+    f32x4_t o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    int kv_end = a.kv_len;
+    if (a.causal_br) {
+        const int lim = q0 + kBQ - 1 + shift + 1;  // one past the last key any row of this block sees
+        if (lim < kv_end) kv_end = lim;
+        if (kv_end < 0) kv_end = 0;
+    }
+
+    for (int t0 = 0; t0 < kv_end; t0 += kBKV) {
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile [key][d] and V tile transposed [d][key] ------------------------------
+        constexpr int PPR = HD / V;  // packs per key row
+        for (int p = tid; p < kBKV * PPR; p += 256) {
+            const int key = p / PPR, c = p % PPR, d = c * V;
+            const int kg = t0 + key;
+            const bool ok = kg < a.kv_len && d < hd;
+            const uint4 kk = ok ? ld16(kp + (int64_t)kg * a.k_ss + d) : make_uint4(0, 0, 0, 0);
+            st16(Ks + key * KS + d, kk);
+            const uint4 vv = ok ? ld16(vp + (int64_t)kg * a.v_ss + d) : make_uint4(0, 0, 0, 0);
+            const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) Vt[(d + j) * VS + key] = ve[j];
+        }
+        __syncthreads();
+
+        // ---- S^T tile: 4 key blocks x (16 keys x 16 queries) --------------------------------------
+        f32x4_t s[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            s[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (V == 8) {
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) {
+                    const uint4 kf = ld16(Ks + (kb * 16 + l15) * KS + ks * 32 + grp * 8);
+                    s[kb] = AttnMma<T>::run(kf, qf[ks], s[kb]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < HD / 4; ++kk) {
+                    const float kf = ((const float*)Ks)[(kb * 16 + l15) * KS + kk * 4 + grp];
+                    s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qs[kk], s[kb], 0, 0, 0);
+                }
+            }
+        }
+        // lane now holds S[qi][key = t0 + kb*16 + grp*4 + r]
+        float tmax = -1e30f;
+        bool msk[NKB][4];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kg = t0 + kb * 16 + grp * 4 + r;
+                const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi + shift);
+                msk[kb][r] = ok;
+                const float sv = ok ? s[kb][r] * a.scale : -1e30f;
+                s[kb][r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = msk[kb][r] ? expf(s[kb][r] - m_new) : 0.f;
+                s[kb][r] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
+
+        // ---- O^T += V^T · P^T ------------------------------------------------------------------------
+        if constexpr (V == 8) {
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+                // k-slots of lane group g: j<4 -> key kb0*16+g*4+j ; j>=4 -> key kb1*16+g*4+(j-4)
+                float pf[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pf[r] = s[2 * kp2][r]; pf[4 + r] = s[2 * kp2 + 1][r]; }
+                const uint4 pfrag = pack<T>(pf);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const T* vrow = Vt + (db * 16 + l15) * VS + grp * 4;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vrow + (2 * kp2) * 16);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + (2 * kp2 + 1) * 16);
+                    const uint4 vfrag = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                    o[db] = AttnMma<T>::run(vfrag, pfrag, o[db]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const float vf = ((const float*)Vt)[(db * 16 + l15) * VS + kb * 16 + grp * 4 + r];
+                        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kb][r], o[db], 0, 0, 0);
+                    }
+        }
+    }
+
+    // ---- epilogue: lane holds O[qi][d = db*16 + grp*4 + r] -------------------------------------------
+    if (qi < a.q_len) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi * a.o_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int d = db * 16 + grp * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (d + r < hd) Tr<T>::st(op + d + r, o[db][r] * inv);
+        }
+    }
+}
+
+template <typename T, int HD>
+static int flash_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    const size_t lds = ((size_t)kBKV * (HD + V) + (size_t)HD * (kBKV + V)) * sizeof(T);
+    dim3 grid((unsigned)cdiv(a.q_len, kBQ), (unsigned)(batch * a.n_heads));
+    hipLaunchKernelGGL((flash_attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
+    SS_LAUNCH_CHECK("flash_attn");
+    return SS_OK;
+}
+
+template <typename T>
+int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    SS_REQUIRE(a.hd % V == 0 && a.hd > 0 && a.hd <= 128, "attention: head_dim %d unsupported", a.hd);
+    SS_REQUIRE(a.q_ss % V == 0 && a.k_ss % V == 0 && a.v_ss % V == 0 && a.q_sh % V == 0 && a.k_sh % V == 0 &&
+                   a.v_sh % V == 0 && a.q_sb % V == 0 && a.k_sb % V == 0 && a.v_sb % V == 0,
+               "attention: strides must be multiples of %d elements", V);
+    SS_REQUIRE(!a.causal_br || a.kv_len >= a.q_len, "attention: causal needs kv_len >= q_len");
+    if (a.q_len == 0 || batch == 0) return SS_OK;
+    SS_REQUIRE(a.kv_len > 0, "attention: kv_len == 0");
+    if (a.hd <= 64) return flash_launch_hd<T, 64>(a, batch, s);
+    return flash_launch_hd<T, 128>(a, batch, s);
+}
+
+int attention_dev(const AttnArgs& a, int64_t batch, int dtype, hipStream_t s) {
+    return SS_DISPATCH(dtype, attention_launch, a, batch, s);
+}
+
+// --------------------------------------------------------------------------------------------
+// (2) decode attention (q_len = 1), split-KV
+// --------------------------------------------------------------------------------------------
+// partial record per (head, split): [m, l, o[hd]] fp32
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, float* __restrict__ part,
+                                                          const int32_t* __restrict__ kv_len_dev, int kv_len_add,
+                                                          const int32_t* __restrict__ done_flag, int hd,
+                                                          int cache_cap, int nsplit, int chunk_cap, float scale) {
+    constexpr int V = Tr<T>::kVec;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw);  // [chunk_cap] scores / probabilities
+    float* red = sc + chunk_cap;                     // [16]
+    float* osum = red + 16;                          // [4][hd]
+    if (done_flag && *done_flag) return;
+    const int h = blockIdx.x, sp = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kv_len = *kv_len_dev + kv_len_add;
+    const int chunk = (kv_len + nsplit - 1) / nsplit;
+    const int k_lo = sp * chunk;
+    const int k_hi = min(kv_len, k_lo + chunk);
+    const int n = max(0, k_hi - k_lo);
+    const int LPK = hd / V;        // lanes per key
+    const int KPW = 64 / LPK;      // keys per wave per iteration
+    const int sub = lane / LPK, dl = lane % LPK;
+    float* rec = part + ((int64_t)h * nsplit + sp) * (hd + 2);
+
+    uint4 qv = ld16(q + (int64_t)h * hd + dl * V);
+    const T* kh = kc + (int64_t)h * cache_cap * hd;
+    const T* vh = vc + (int64_t)h * cache_cap * hd;
+
+    // ---- scores ------------------------------------------------------------------------------------
+    float lmax = -1e30f;
+    for (int i = wid * KPW + sub; i < n; i += 4 * KPW) {
+        const uint4 kk = ld16(kh + (int64_t)(k_lo + i) * hd + dl * V);
+        float d = dot_pack<T>(kk, qv, 0.f);
+        for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        d *= scale;
+        if (dl == 0) sc[i] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    const float m = block_max(lmax, red);
+    // ---- probabilities (fp32, like the oracle's softmax) ------------------------------------------------
+    float ls = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float p = expf(sc[i] - m);
+        sc[i] = p;
+        ls += p;
+    }
+    const float l = block_sum(ls, red);  // (contains the barriers that publish sc[])
+    // ---- PV ----------------------------------------------------------------------------------------
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int i = wid * KPW + sub; i < n; i += 4 * KPW) {
+        float vf[V];
+        unpack<T>(ld16(vh + (int64_t)(k_lo + i) * hd + dl * V), vf);
+        const float p = sc[i];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+        for (int o = LPK; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) osum[wid * hd + dl * V + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < hd) rec[2 + tid] = osum[tid] + osum[hd + tid] + osum[2 * hd + tid] + osum[3 * hd + tid];
+    if (tid == 0) { rec[0] = n > 0 ? m : -1e30f; rec[1] = n > 0 ? l : 0.f; }
+}
+
+template <typename T>
+__global__ void attn_combine_kernel(const float* __restrict__ part, T* __restrict__ out,
+                                    const int32_t* __restrict__ done_flag, int hd, int nsplit) {
+    if (done_flag && *done_flag) return;
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float* rec = part + (int64_t)h * nsplit * (hd + 2);
+    float m = -1e30f;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, rec[s * (hd + 2)]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* r = rec + s * (hd + 2);
+        const float w = r[1] > 0.f ? expf(r[0] - m) : 0.f;
+        l = fmaf(w, r[1], l);
+        o = fmaf(w, r[2 + d], o);
+    }
+    Tr<T>::st(out + (int64_t)h * hd + d, o / l);
+}
+
+static inline int decode_nsplit() { return tuning_get("attn_decode_nsplit", 8); }
+
+template <typename T>
+int attn_decode_launch(const void* q, const void* kc, const void* vc, void* out, void* ws, const int32_t* kv_len_dev,
+                       int kv_len_add, const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap,
+                       hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    SS_REQUIRE(hd % V == 0 && 64 % (hd / V) == 0 && hd <= 256, "attn_decode: head_dim %lld unsupported", (long long)hd);
+    const int nsplit = decode_nsplit();
+    const int chunk_cap = cdiv(cache_cap + 1, nsplit) + 1;
+    const size_t lds = ((size_t)chunk_cap + 16 + 4 * hd) * sizeof(float);
+    SS_REQUIRE(lds <= 150 * 1024, "attn_decode: cache_cap %lld too large for nsplit %d", (long long)cache_cap, nsplit);
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL(attn_decode_kernel<T>, dim3((unsigned)n_heads, (unsigned)nsplit), dim3(256), lds, s,
+                       (const T*)q, (const T*)kc, (const T*)vc, (float*)ws, kv_len_dev, kv_len_add, done_flag,
+                       (int)hd, (int)cache_cap, nsplit, chunk_cap, scale);
+    SS_LAUNCH_CHECK("attn_decode");
+    hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((unsigned)n_heads), dim3((unsigned)hd), 0, s, (const float*)ws,
+                       (T*)out, done_flag, (int)hd, nsplit);
+    SS_LAUNCH_CHECK("attn_combine");
+    return SS_OK;
+}
+
+int attn_decode_dev(const void* q, const void* kc, const void* vc, void* out, void* ws, const int32_t* kv_len_dev,
+                    int kv_len_add, const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap,
+                    int dtype, hipStream_t s) {
+    return SS_DISPATCH(dtype, attn_decode_launch, q, kc, vc, out, ws, kv_len_dev, kv_len_add, done_flag, n_heads, hd,
+                       cache_cap, s);
+}
+
+}  // namespace ss
+
+using namespace ss;
+
+extern "C" {
+
+int ss_attention(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t n_heads,
+                 int64_t q_len, int64_t kv_len, int64_t hd, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                 int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh,
+                 int64_t o_ss, float scale, int causal_br, int dtype, void* stream) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out;
+    a.q_len = (int)q_len; a.kv_len = (int)kv_len; a.hd = (int)hd; a.n_heads = (int)n_heads;
+    a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
+    a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_sh = o_sh; a.o_ss = o_ss;
+    a.scale = scale; a.causal_br = causal_br;
+    return attention_dev(a, batch, dtype, (hipStream_t)stream);
+}
+
+size_t ss_attn_decode_workspace_bytes(int64_t n_heads, int64_t hd) {
+    return (size_t)n_heads * 64 /* max nsplit */ * (size_t)(hd + 2) * sizeof(float);
+}
+
+int ss_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, void* workspace,
+                   const int32_t* kv_len_dev, int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype,
+                   void* stream) {
+    return attn_decode_dev(q, kcache, vcache, out, workspace, kv_len_dev, 0, nullptr, n_heads, hd, cache_cap, dtype,
+                           (hipStream_t)stream);
+}
+
+}  // extern "C"

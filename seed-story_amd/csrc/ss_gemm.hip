@@ -1,0 +1,229 @@
+// C[M,N] = A[M,K] · W[N,K]^T (+bias)(+GELU)(+residual) on the CDNA4 matrix cores.
+//
+// Every nn.Linear on the hot path has this shape with BOTH operands K-contiguous
+// (modeling_llama_xformer.py:228-230,297,191; qwen_visual.py:191,196,259; resampler.py),
+// which is exactly the MFMA fragment shape: lane l of a wave supplies 8 consecutive k of
+// row (l & 15) for k-group (l >> 4).
+//
+// Operand roles are swapped w.r.t. the math so that stores vectorise: the MFMA "A" operand
+// is the WEIGHT tile (rows -> n) and the "B" operand the ACTIVATION tile (cols -> m), so a
+// lane ends up with C[m = l&15][n = 4*(l>>4) .. +3]: four consecutive n per row = one 8-byte
+// (bf16) / 16-byte (fp32) store, bias is a per-lane 4-vector and the residual one load.
+//
+//   bf16 / fp16 : v_mfma_f32_16x16x32_{bf16,f16}, BK = 64
+//   fp32        : v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain; the CPU-parity mode), BK = 32
+//
+// Tiles: <BM, BN, WM, WN> = block tile (activation rows x weight rows) and the wave grid.
+// Global -> register -> LDS staging with the next tile's loads in flight during the MFMAs
+// (guide T14 write-late form), padded LDS rows (+1 pack) to break the 128-byte stride.
+#include "ss_common.h"
+
+namespace ss {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int kK = 32;
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    static constexpr int kK = 32;
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+struct GemmArgs {
+    const void* A; const void* W; void* C; const void* bias; const void* residual;
+    int M, N, K;
+    int64_t lda, ldw, ldc, ldr;
+    int epi;
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int BK = 8 * V;            // 8 packs per tile row
+    constexpr int LS = BK + V;           // padded LDS row stride (elements)
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int PA = (BM * 8 + 255) / 256, PW = (BN * 8 + 255) / 256;  // packs per thread per tile
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be MFMA-shaped");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);
+    T* Ws = As + BM * LS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ W = (const T*)g.W;
+    const int K = g.K, M = g.M, N = g.N;
+    const int ntiles = (K + BK - 1) / BK;
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[PA], rw[PW];
+    auto load_tile = [&](int t) {
+        const int k0 = t * BK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int p = tid + i * 256;
+            const int r = p >> 3, c = p & 7;
+            const int m = m_blk + r, k = k0 + c * V;
+            ra[i] = (p < BM * 8 && m < M && k < K) ? ld16(A + (int64_t)m * g.lda + k) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int p = tid + i * 256;
+            const int r = p >> 3, c = p & 7;
+            const int n = n_blk + r, k = k0 + c * V;
+            rw[i] = (p < BN * 8 && n < N && k < K) ? ld16(W + (int64_t)n * g.ldw + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int p = tid + i * 256;
+            if (p < BM * 8) st16(As + (p >> 3) * LS + (p & 7) * V, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int p = tid + i * 256;
+            if (p < BN * 8) st16(Ws + (p >> 3) * LS + (p & 7) * V, rw[i]);
+        }
+    };
+
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);  // in flight while the MFMAs run
+        if constexpr (V == 8) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                uint4 fw[FN], fa[FM];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fw[i] = ld16(Ws + (wn * TN + i * 16 + l15) * LS + ks * 32 + grp * 8);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) fa[j] = ld16(As + (wm * TM + j * 16 + l15) * LS + ks * 32 + grp * 8);
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = Mma<T>::run(fw[i], fa[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float fw[FN], fa[FM];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fw[i] = ((const float*)Ws)[(wn * TN + i * 16 + l15) * LS + kk * 4 + grp];
+#pragma unroll
+                for (int j = 0; j < FM; ++j) fa[j] = ((const float*)As)[(wm * TM + j * 16 + l15) * LS + kk * 4 + grp];
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = .. + l15][n = .. + grp*4 + r] -------------------------------
+    T* __restrict__ C = (T*)g.C;
+    const T* bias = (const T*)g.bias;
+    const T* res = (const T*)g.residual;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n0 = n_blk + wn * TN + i * 16 + grp * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.epi & SS_EPI_BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < N) bv[r] = Tr<T>::ld(bias + n0 + r);
+        }
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m_blk + wm * TM + j * 16 + l15;
+            if (m >= M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[i][j][r] + bv[r];
+                if (g.epi & SS_EPI_GELU) t = gelu_erf(Tr<T>::rnd(t));  // Linear output is rounded, then GELU
+                v[r] = Tr<T>::rnd(t);
+            }
+            if (g.epi & SS_EPI_RESIDUAL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < N) Tr<T>::st(C + (int64_t)m * g.ldc + n0 + r, v[r]);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int LS = 8 * V + V;
+    const size_t lds = (size_t)(BM + BN) * LS * sizeof(T);
+    dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, s, g);
+    SS_LAUNCH_CHECK("gemm");
+    return SS_OK;
+}
+
+template <typename T>
+int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    SS_REQUIRE(K % V == 0 && lda % V == 0 && ldw % V == 0, "gemm: K/lda/ldw must be multiples of %d (K=%lld)", V,
+               (long long)K);
+    SS_REQUIRE(!(epi & SS_EPI_SILU_MUL), "gemm: SILU_MUL is a GEMV epilogue (use ss_silu_mul)");
+    SS_REQUIRE(!(epi & SS_EPI_BIAS) || bias, "gemm: bias epilogue without bias");
+    SS_REQUIRE(!(epi & SS_EPI_RESIDUAL) || residual, "gemm: residual epilogue without residual");
+    if (M == 0 || N == 0) return SS_OK;
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.residual = residual;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
+    const int force = tuning_get("gemm_cfg", 0);
+    const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+    int cfg;
+    if (force) cfg = force;
+    else if (M <= 128) cfg = 3;                 // weight streaming: many narrow-N blocks
+    else if (big_blocks >= 200) cfg = 1;
+    else cfg = 2;
+    switch (cfg) {
+        case 1: return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
+        case 2: return gemm_launch_cfg<T, 64, 64, 2, 2>(g, s);
+        default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
+    }
+}
+
+int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+             int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, int dtype, hipStream_t s) {
+    return SS_DISPATCH(dtype, gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epi, s);
+}
+
+}  // namespace ss
+
+extern "C" int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int64_t ldw, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue,
+                       int dtype, void* stream) {
+    return ss::gemm_dev(A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue, dtype, (hipStream_t)stream);
+}

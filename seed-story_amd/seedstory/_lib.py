@@ -1,0 +1,122 @@
+"""ctypes binding of ``libseedstory_hip.so`` (the C ABI declared in ``include/seedstory_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  The product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SEEDSTORY_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libseedstory_hip.so"))
+
+SS_F32, SS_BF16, SS_F16 = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SILU_MUL = 0, 1, 2, 4, 8
+
+vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+i32p = C.POINTER(C.c_int32)
+
+
+class SSError(RuntimeError):
+    pass
+
+
+class LlamaConfig(C.Structure):
+    _fields_ = [("hidden", i32), ("n_heads", i32), ("n_layers", i32), ("inter", i32), ("vocab", i32),
+                ("max_pos", i32), ("rms_eps", f32), ("dtype", i32), ("cache_cap", i32), ("max_new", i32),
+                ("n_img_ids", i32), ("eos_id", i32)]
+
+
+class LlamaLayerWeights(C.Structure):
+    _fields_ = [("wqkv", vp), ("wo", vp), ("wgu", vp), ("wdown", vp), ("ln1", vp), ("ln2", vp)]
+
+
+class LlamaWeights(C.Structure):
+    _fields_ = [("embed", vp), ("lm_head", vp), ("final_norm", vp), ("rope_cos", vp), ("rope_sin", vp),
+                ("layers", C.POINTER(LlamaLayerWeights))]
+
+
+class ResamplerWeights(C.Structure):
+    _fields_ = [("q_in", vp), ("pos_kv", vp), ("kv_proj", vp), ("ln_kv_w", vp), ("ln_kv_b", vp), ("in_w", vp),
+                ("in_b", vp), ("out_w", vp), ("out_b", vp), ("nq", i32), ("embed", i32), ("n_heads", i32),
+                ("kv_dim", i32), ("l_kv", i32), ("ln_eps", f32)]
+
+
+class VitLayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "in_w", "in_b", "out_w", "out_b", "fc_w",
+                                  "fc_b", "proj_w", "proj_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("conv_w", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp),
+                ("layers", C.POINTER(VitLayerWeights)), ("width", i32), ("n_layers", i32), ("n_heads", i32),
+                ("mlp_width", i32), ("patch", i32), ("image", i32), ("kpad", i32), ("ln_eps", f32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/seedstory_hip.h
+PROTOTYPES = {
+    "ss_last_error": (C.c_char_p, []),
+    "ss_abi_version": (C.c_int, []),
+    "ss_device_info": (C.c_int, [i32p]),
+    "ss_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "ss_get_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "ss_rmsnorm": (C.c_int, [vp, vp, vp, i64, i64, f32, C.c_int, vp]),
+    "ss_layernorm": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, C.c_int, vp]),
+    "ss_add_bcast": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "ss_silu_mul": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),
+    "ss_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
+    "ss_scatter_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
+    "ss_im2col_patch": (C.c_int, [vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "ss_l2normalize_dim1": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, vp]),
+    "ss_rope_kv_append": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, C.c_int, vp]),
+    "ss_attention": (C.c_int, [vp, vp, vp, vp] + [i64] * 17 + [f32, C.c_int, C.c_int, vp]),
+    "ss_attn_decode_workspace_bytes": (sz, [i64, i64]),
+    "ss_attn_decode": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "ss_gemm": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, C.c_int, vp]),
+    "ss_gemv": (C.c_int, [vp, vp, vp, i64, i64, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
+    "ss_imgproc_argmax": (C.c_int, [vp, i64, vp, vp, i64, vp, C.c_int, vp]),
+    "ss_llama_workspace_bytes": (sz, [C.POINTER(LlamaConfig), i64]),
+    "ss_llama_create": (C.c_int, [C.POINTER(LlamaConfig), C.POINTER(LlamaWeights), vp, sz, i64, i32p,
+                                  C.POINTER(vp)]),
+    "ss_llama_destroy": (None, [vp]),
+    "ss_llama_buffer": (vp, [vp, C.c_int]),
+    "ss_llama_set_lengths": (C.c_int, [vp, i64, i64, vp]),
+    "ss_llama_get_lengths": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    "ss_llama_kv_gather": (C.c_int, [vp, vp, i64, vp]),
+    "ss_llama_prefill": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "ss_llama_generate": (C.c_int, [vp, i64, i32, i32p, i64, C.POINTER(i64), vp]),
+    "ss_llama_profile_decode": (C.c_int, [vp, i64, C.POINTER(f32), C.POINTER(C.c_double), vp]),
+    "ss_resampler_workspace_bytes": (sz, [C.POINTER(ResamplerWeights), i64, C.c_int]),
+    "ss_resampler_forward": (C.c_int, [C.POINTER(ResamplerWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
+    "ss_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i64, C.c_int]),
+    "ss_vit_forward": (C.c_int, [C.POINTER(VitWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it was not built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SSError("libseedstory_hip.so not found at %s — build it first (seed-story_amd/csrc/Makefile); "
+                          "there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.ss_abi_version() != 1:
+            raise SSError("ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ss_last_error()
+        raise SSError("%s failed (%d): %s" % (what or "seedstory call", rc, msg.decode() if msg else "?"))
+
+
+def set_tuning(key: str, value: int):
+    check(lib().ss_set_tuning(key.encode(), int(value)), "ss_set_tuning")

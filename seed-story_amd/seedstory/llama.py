@@ -1,0 +1,225 @@
+"""Python handle on the native LLaMA decoder engine (``ss_llama_*`` in the C ABI).
+
+Owns the device memory (torch tensors) the engine works in — merged/concatenated weights, the
+KV-cache slab and activation workspace — and exposes the KV cache in the reference's layout
+(``past_key_values``: tuple over layers of ``(k, v)`` each ``[1, n_heads, len, head_dim]``, keys
+post-RoPE) as zero-copy views.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, lib
+
+ATTN_PROJ = ("q_proj", "k_proj", "v_proj", "o_proj")
+MLP_PROJ = ("gate_proj", "up_proj", "down_proj")
+
+
+def rope_tables(head_dim, max_pos, dtype, base=10000.0):
+    """cos/sin tables of LlamaRotaryEmbedding (modeling_llama_xformer.py:118-134): fp32
+    ``cat(freqs, freqs)``, cast to the model dtype by the module-level ``.to(dtype)``."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _merged(sd, name, dtype, device, lora_scaling):
+    """W (+ (alpha/r) B A when LoRA factors are present), merged in fp32 on the device."""
+    w = sd[name + ".weight"].to(device=device)
+    a = sd.get(name + ".lora_A.weight", sd.get(name + ".lora_A.default.weight"))
+    b = sd.get(name + ".lora_B.weight", sd.get(name + ".lora_B.default.weight"))
+    if a is not None and b is not None:
+        w = w.float() + lora_scaling * (b.to(device=device).float() @ a.to(device=device).float())
+    return w.to(dtype).contiguous()
+
+
+class LlamaEngine:
+    def __init__(self, state_dict, *, hidden, n_heads, n_layers, inter, vocab, dtype=torch.bfloat16, device="cuda:0",
+                 rms_eps=1e-5, max_pos=4096, cache_cap=2048, max_new=512, max_prefill_rows=1024, img_ids=(),
+                 eos_id=2, lora_scaling=2.0):
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab = hidden, n_heads, n_layers, inter, vocab
+        self.hd = hidden // n_heads
+        self.cache_cap, self.max_new, self.max_rows = cache_cap, max_new, max_prefill_rows
+        self.img_ids = [int(i) for i in img_ids]
+        self.eos_id = eos_id
+        sd = state_dict
+        dev = self.device
+        self._keep = []  # tensors the engine points into
+
+        def own(t):
+            t = t.to(device=dev, dtype=dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        self.embed = own(sd["model.embed_tokens.weight"])
+        self.lm_head = own(sd["lm_head.weight"])
+        self.final_norm = own(sd["model.norm.weight"])
+        cos, sin = rope_tables(self.hd, max_pos, dtype)
+        self.rope_cos, self.rope_sin = own(cos), own(sin)
+        layers = (_lib.LlamaLayerWeights * n_layers)()
+        for l in range(n_layers):
+            pfx = "model.layers.%d." % l
+            q, k, v, o = (_merged(sd, pfx + "self_attn." + n, dtype, dev, lora_scaling) for n in ATTN_PROJ)
+            g, u, d = (_merged(sd, pfx + "mlp." + n, dtype, dev, lora_scaling) for n in MLP_PROJ)
+            wqkv = torch.cat([q, k, v], dim=0).contiguous()
+            wgu = torch.cat([g, u], dim=0).contiguous()
+            ln1 = own(sd[pfx + "input_layernorm.weight"])
+            ln2 = own(sd[pfx + "post_attention_layernorm.weight"])
+            self._keep += [wqkv, o, wgu, d]
+            layers[l] = _lib.LlamaLayerWeights(wqkv.data_ptr(), o.data_ptr(), wgu.data_ptr(), d.data_ptr(),
+                                               ln1.data_ptr(), ln2.data_ptr())
+            del q, k, v, g, u
+        self._layers = layers
+        self._init_engine(max_pos, rms_eps)
+
+    @classmethod
+    def from_prebuilt(cls, *, embed, lm_head, final_norm, layers, hidden, n_heads, n_layers, inter, vocab,
+                      dtype=torch.bfloat16, device="cuda:0", rms_eps=1e-5, max_pos=4096, cache_cap=2048, max_new=512,
+                      max_prefill_rows=1024, img_ids=(), eos_id=2):
+        """Engine over already merged/concatenated device tensors: ``layers`` is a list of
+        ``(wqkv, wo, wgu, wdown, ln1, ln2)`` (used by the synthetic-weight benchmark, which
+        creates the 13.5 GB of weights directly on the GPU)."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab = hidden, n_heads, n_layers, inter, vocab
+        self.hd = hidden // n_heads
+        self.cache_cap, self.max_new, self.max_rows = cache_cap, max_new, max_prefill_rows
+        self.img_ids = [int(i) for i in img_ids]
+        self.eos_id = eos_id
+        self.embed, self.lm_head, self.final_norm = embed, lm_head, final_norm
+        cos, sin = rope_tables(self.hd, max_pos, dtype)
+        self.rope_cos, self.rope_sin = cos.to(self.device), sin.to(self.device)
+        self._keep = [embed, lm_head, final_norm, self.rope_cos, self.rope_sin, layers]
+        arr = (_lib.LlamaLayerWeights * n_layers)()
+        for l, t in enumerate(layers):
+            arr[l] = _lib.LlamaLayerWeights(*[x.data_ptr() for x in t])
+        self._layers = arr
+        self._init_engine(max_pos, rms_eps)
+        return self
+
+    def _init_engine(self, max_pos, rms_eps):
+        cfg = _lib.LlamaConfig(self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab, max_pos, rms_eps,
+                               ops.dt(self.dtype), self.cache_cap, self.max_new, len(self.img_ids), self.eos_id)
+        self._cfg = cfg
+        w = _lib.LlamaWeights(self.embed.data_ptr(), self.lm_head.data_ptr(), self.final_norm.data_ptr(),
+                              self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self._layers)
+        nbytes = lib().ss_llama_workspace_bytes(C.byref(cfg), self.max_rows)
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        ids = (C.c_int32 * max(1, len(self.img_ids)))(*self.img_ids)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ss_llama_create(C.byref(cfg), C.byref(w), self._ws.data_ptr(), nbytes, self.max_rows, ids,
+                                        C.byref(h)), "ss_llama_create")
+        self._h = h
+        self._views = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().ss_llama_destroy(h)
+            self._h = None
+
+    # ---- zero-copy views into the engine workspace -------------------------------------------
+    def _buf(self, which, shape, dtype):
+        key = (which, tuple(shape), dtype)
+        if key not in self._views:
+            ptr = lib().ss_llama_buffer(self._h, which)
+            base = self._ws.data_ptr()
+            off = ptr - base
+            n = 1
+            for s in shape:
+                n *= s
+            esz = torch.empty(0, dtype=dtype).element_size()
+            self._views[key] = self._ws[off:off + n * esz].view(dtype).view(*shape)
+        return self._views[key]
+
+    @property
+    def k_cache(self):
+        return self._buf(0, (self.n_layers, self.n_heads, self.cache_cap, self.hd), self.dtype)
+
+    @property
+    def v_cache(self):
+        return self._buf(1, (self.n_layers, self.n_heads, self.cache_cap, self.hd), self.dtype)
+
+    @property
+    def gen_ids(self):
+        return self._buf(2, (self.max_new,), torch.int32)
+
+    @property
+    def hidden_rows(self):
+        return self._buf(3, (self.max_new, self.hidden), self.dtype)
+
+    @property
+    def logits(self):
+        return self._buf(4, (self.vocab,), self.dtype)
+
+    @property
+    def state(self):
+        return self._buf(5, (8,), torch.int32)
+
+    # ---- lengths / cache management --------------------------------------------------------------
+    def lengths(self):
+        kv, pos = C.c_int64(), C.c_int64()
+        check(lib().ss_llama_get_lengths(self._h, C.byref(kv), C.byref(pos)), "ss_llama_get_lengths")
+        return kv.value, pos.value
+
+    def set_lengths(self, kv_len, pos):
+        check(lib().ss_llama_set_lengths(self._h, kv_len, pos, ops.stream()), "ss_llama_set_lengths")
+
+    def reset(self):
+        self.set_lengths(0, 0)
+
+    def past_key_values(self, length=None):
+        """Reference-layout views of the live cache (modeling_llama_xformer.py:239-242)."""
+        n = self.lengths()[0] if length is None else length
+        k, v = self.k_cache, self.v_cache
+        return tuple((k[l, :, :n].unsqueeze(0), v[l, :, :n].unsqueeze(0)) for l in range(self.n_layers))
+
+    def load_past_key_values(self, past, pos=None):
+        """Copy an external reference-layout cache into the slab (no-op for our own views)."""
+        n = past[0][0].shape[2]
+        for l, (k, v) in enumerate(past):
+            dk, dv = self.k_cache[l, :, :n], self.v_cache[l, :, :n]
+            if k.data_ptr() != dk.data_ptr():
+                dk.copy_(k[0])
+            if v.data_ptr() != dv.data_ptr():
+                dv.copy_(v[0])
+        self.set_lengths(n, n if pos is None else pos)
+
+    def kv_gather(self, keep_idx):
+        idx = torch.as_tensor(keep_idx, dtype=torch.int32, device=self.device).contiguous()
+        check(lib().ss_llama_kv_gather(self._h, idx.data_ptr(), idx.numel(), ops.stream()), "ss_llama_kv_gather")
+
+    # ---- forward paths ---------------------------------------------------------------------------------
+    def prefill(self, embeds, pos_ids=None, want_hidden=False):
+        """embeds [M, hidden] rows appended after the cached prefix.  Returns the post-final-norm
+        hidden rows [M, hidden] if want_hidden; the last row's logits land in ``self.logits``."""
+        embeds = embeds.to(device=self.device, dtype=self.dtype).contiguous()
+        M = embeds.shape[0]
+        hid = torch.empty(M, self.hidden, dtype=self.dtype, device=self.device) if want_hidden else None
+        pid = None if pos_ids is None else pos_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        check(lib().ss_llama_prefill(self._h, embeds.data_ptr(), M, ops.p(pid), ops.p(hid), ops.stream()),
+              "ss_llama_prefill")
+        return hid
+
+    def generate(self, n_steps, last_prompt_id, forced=None):
+        """Greedy decode from the current logits; returns the number of generated tokens."""
+        forced = [] if forced is None else [int(t) for t in forced]
+        arr = (C.c_int32 * max(1, len(forced)))(*forced)
+        n = C.c_int64()
+        check(lib().ss_llama_generate(self._h, n_steps, int(last_prompt_id), arr, len(forced), C.byref(n),
+                                      ops.stream()), "ss_llama_generate")
+        return n.value
+
+    def profile_decode(self, n_tokens=4):
+        ms = (C.c_float * 8)()
+        by = (C.c_double * 2)()
+        check(lib().ss_llama_profile_decode(self._h, n_tokens, ms, by, ops.stream()), "ss_llama_profile_decode")
+        return {"gemv_ms": ms[0], "attn_ms": ms[1], "rope_ms": ms[2], "misc_ms": ms[3], "token_ms": ms[4],
+                "gemv_bytes": by[0], "kv_bytes_per_pos": by[1]}

@@ -1,0 +1,251 @@
+"""MI355X-native drop-in for the reference's ``src/models_clm/modeling_llama_xformer.py``.
+
+``LlamaForCausalLM`` keeps the reference's surface that the hot path touches:
+``from_pretrained(path, low_cpu_mem_usage, torch_dtype)``, HF parameter names
+(``model.embed_tokens.weight`` … ``lm_head.weight``), ``get_input_embeddings()``,
+``resize_token_embeddings()``, and the mutable attributes ``use_kv_cache_head`` /
+``kv_cache_head`` / ``past_key_values`` (reference :676-678) that the drivers poke
+(gen_george.py:165, vis_george_sink.py:171-173,244,293).
+
+The decoder stack itself (reference LlamaRMSNorm :97-115, rotary :118-173, LlamaAttention
+:217-301 with xformers FMHA, LlamaMLP :176-191, LlamaModel.forward :532-666) runs inside the
+native engine (``seedstory.llama.LlamaEngine`` -> ``ss_llama_*``): there is no torch compute
+here and no CPU path.
+"""
+import json
+import os
+
+import torch
+from torch import nn
+
+from seedstory.llama import LlamaEngine
+
+
+class LlamaConfig:
+    """The handful of transformers.LlamaConfig fields the path needs."""
+
+    def __init__(self, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                 vocab_size=32000, max_position_embeddings=4096, rms_norm_eps=1e-5, eos_token_id=2, bos_token_id=1,
+                 **kwargs):
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.vocab_size = vocab_size
+        self.max_position_embeddings = max_position_embeddings
+        self.rms_norm_eps = rms_norm_eps
+        self.eos_token_id = eos_token_id
+        self.bos_token_id = bos_token_id
+        self.use_cache = True
+
+    @classmethod
+    def from_pretrained(cls, path):
+        with open(os.path.join(path, "config.json")) as f:
+            return cls(**json.load(f))
+
+
+class _W(nn.Module):
+    def __init__(self, o, i):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i), requires_grad=False)
+
+
+class _Norm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d), requires_grad=False)
+
+
+class _Attn(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = _W(h, h), _W(h, h), _W(h, h), _W(h, h)
+
+
+class _MLP(nn.Module):
+    def __init__(self, h, i):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = _W(i, h), _W(i, h), _W(h, i)
+
+
+class _Layer(nn.Module):
+    def __init__(self, h, i):
+        super().__init__()
+        self.self_attn = _Attn(h)
+        self.mlp = _MLP(h, i)
+        self.input_layernorm = _Norm(h)
+        self.post_attention_layernorm = _Norm(h)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, v, h):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(v, h), requires_grad=False)
+
+    def forward(self, input_ids):
+        from seedstory import ops
+        shape = tuple(input_ids.shape)
+        rows = ops.gather_rows(self.weight.data, input_ids.reshape(-1))
+        return rows.view(*shape, self.weight.shape[1])
+
+
+class _Model(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embed_tokens = _Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([_Layer(cfg.hidden_size, cfg.intermediate_size)
+                                     for _ in range(cfg.num_hidden_layers)])
+        self.norm = _Norm(cfg.hidden_size)
+
+
+class LlamaForCausalLM(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = _Model(config)
+        self.lm_head = _W(config.vocab_size, config.hidden_size)
+        self.past_key_values = None
+        self.kv_cache_head = None
+        self.use_kv_cache_head = True
+        self._engine = None
+        self._engine_sig = None
+        # engine sizing knobs (KV slots, generated-token ring, rows per prefill call)
+        self.cache_cap = 2048
+        self.max_new = 512
+        self.max_prefill_rows = 1280
+
+    # ---- reference surface ------------------------------------------------------------------
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def resize_token_embeddings(self, vocab_size):
+        """Grow/shrink embed_tokens and lm_head rows (peft_models.py:43-45); new rows keep the
+        mean of the old table like HF's default initialiser is NOT reproduced (random there)."""
+        for holder in (self.model.embed_tokens, self.lm_head):
+            old = holder.weight.data
+            new = torch.zeros(vocab_size, old.shape[1], dtype=old.dtype, device=old.device)
+            n = min(vocab_size, old.shape[0])
+            new[:n] = old[:n]
+            holder.weight = nn.Parameter(new, requires_grad=False)
+        self.config.vocab_size = vocab_size
+        self._engine = None
+        return self.model.embed_tokens
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, low_cpu_mem_usage=True, torch_dtype=None, **kwargs):
+        """Loads an HF LLaMA folder (config.json + *.safetensors / pytorch_model*.bin)."""
+        cfg = LlamaConfig.from_pretrained(pretrained_model_name_or_path)
+        model = cls(cfg)
+        sd = {}
+        folder = pretrained_model_name_or_path
+        for fn in sorted(os.listdir(folder)):
+            full = os.path.join(folder, fn)
+            if fn.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd.update(load_file(full))
+            elif fn.startswith("pytorch_model") and fn.endswith(".bin"):
+                sd.update(torch.load(full, map_location="cpu"))
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        print("llama: missing keys:", len(missing), "unexpected keys:", len(unexpected))
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        return model
+
+    def init_synthetic(self, seed=0, std=0.02):
+        """N(0, 0.02) weights like the reference ``_init_weights`` (:399-408), on the current device."""
+        for name, p in self.named_parameters():
+            if p.dim() == 1:
+                p.data.fill_(1.0)
+            elif p.is_cuda:
+                p.data.normal_(0.0, std)
+            else:
+                g = torch.Generator().manual_seed(seed + hash(name) % 10007)
+                p.data.copy_(torch.randn(p.shape, generator=g) * std)
+        self._engine = None
+        return self
+
+    # ---- engine --------------------------------------------------------------------------------
+    # ---- generation (HF-4.34 greedy search semantics) -------------------
+    def collect_flat_state(self):
+        """HF-named flat weights for the engine: unwraps the peft-style children that
+        ``get_peft_model_with_resize_embedding`` grafts on (LoRA factors, modules_to_save norms)."""
+        flat = {}
+        for name, prm in self.named_parameters():
+            if ".original_module." in name:
+                continue
+            name = name.replace(".modules_to_save.default.", ".")
+            flat[name] = prm.data
+        return flat
+
+    def engine_for_generation(self, img_ids):
+        lora = getattr(self, "_lora_scaling", None)
+        p0 = self.lm_head.weight
+        sig = (p0.data_ptr(), p0._version, p0.dtype, str(p0.device), tuple(img_ids), self.cache_cap, self.max_new,
+               self.max_prefill_rows)
+        if self._engine is None or self._engine_sig != sig:
+            if not p0.is_cuda:
+                raise RuntimeError("LlamaForCausalLM must be moved to the GPU first (no CPU path)")
+            c = self.config
+            self._engine = LlamaEngine(self.collect_flat_state(), hidden=c.hidden_size,
+                                       n_heads=c.num_attention_heads, n_layers=c.num_hidden_layers,
+                                       inter=c.intermediate_size, vocab=c.vocab_size, dtype=p0.dtype, device=p0.device,
+                                       rms_eps=c.rms_norm_eps, max_pos=c.max_position_embeddings,
+                                       cache_cap=self.cache_cap, max_new=self.max_new,
+                                       max_prefill_rows=self.max_prefill_rows, img_ids=img_ids,
+                                       eos_id=c.eos_token_id, lora_scaling=lora if lora is not None else 2.0)
+            self._engine_sig = sig
+        return self._engine
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, inputs_embeds=None, logits_processor=None, past_key_values=None,
+                 max_new_tokens=120, output_hidden_states=True, return_dict_in_generate=True, forced_tokens=None,
+                 **unused):
+        """Greedy search as ``ContinuousLVLM.generate`` drives it (reference models.py:146-153):
+        ``inputs_embeds`` feed step 0, ``input_ids`` is the running sequence, ``do_sample=False``
+        (temperature / top_p are inert), the image-token logits processor is applied on device."""
+        img_ids = ()
+        for proc in (logits_processor or []):
+            img_ids = tuple(getattr(proc, "img_ids_list", ()))
+        eng = self.engine_for_generation(img_ids)
+        dev = eng.device
+        input_ids = input_ids.to(dev)
+        S = input_ids.shape[1]
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        rows = inputs_embeds[0]
+        if past_key_values is None:
+            eng.reset()
+            fed0 = S
+            hid0 = eng.prefill(rows, want_hidden=output_hidden_states)
+        else:
+            head = self.kv_cache_head if (self.use_kv_cache_head and self.kv_cache_head is not None) else S - 1
+            eng.load_past_key_values(past_key_values)
+            fed0 = S - head
+            pos = torch.arange(head, S, dtype=torch.int32, device=dev)      # cumsum(mask)-1 sliced (:811-816)
+            hid0 = eng.prefill(rows[head:], pos_ids=pos, want_hidden=output_hidden_states)
+            eng.set_lengths(eng.lengths()[0], S)
+        n = eng.generate(max_new_tokens, int(input_ids[0, -1]), forced_tokens)
+        gen = eng.gen_ids[:n].to(torch.long)
+        sequences = torch.cat([input_ids[0], gen]).unsqueeze(0)
+        hidden_states = None
+        if output_hidden_states:
+            steps = [(hid0.unsqueeze(0),)]
+            hr = eng.hidden_rows[:max(n - 1, 0)]
+            steps += [(hr[j].view(1, 1, -1),) for j in range(hr.shape[0])]
+            hidden_states = tuple(steps)
+        self.past_key_values = eng.past_key_values()
+        if self.use_kv_cache_head:
+            adv = fed0 + max(n - 1, 0)
+            self.kv_cache_head = adv if self.kv_cache_head is None else self.kv_cache_head + adv
+        return GenerateOutput(sequences=sequences, hidden_states=hidden_states, attentions=None)
+
+
+class GenerateOutput:
+    def __init__(self, sequences, hidden_states, attentions):
+        self.sequences = sequences
+        self.hidden_states = hidden_states
+        self.attentions = attentions

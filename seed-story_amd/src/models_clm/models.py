@@ -1,0 +1,108 @@
+"""MI355X-native drop-in for the reference's ``src/models_clm/models.py`` (inference part).
+
+``ContinuousLVLM`` keeps the constructor, ``from_pretrained`` and ``generate`` signatures and
+the returned dict keys of the reference (models.py:20-31, 98-230).  ``generate`` does what the
+reference does — embed + splice image features (:127-135), greedy decode with the image-token
+logits processor (:137-153), slice the 64 last-layer states in front of the last ``</img>``
+(:182-197) and regress them to a 256x4096 ViT-space feature with the output resampler (:205) —
+but every tensor op is a HIP kernel of libseedstory_hip.so and the T-iteration decode loop runs
+from one hipGraph with no per-token host sync.  Training ``forward`` (:33-96) is out of scope.
+"""
+import torch
+from torch import nn
+
+from seedstory import ops
+
+from .generation import AutoImageTokenGenerationProcessor, LogitsProcessorList
+
+BOI_TOKEN = '<img>'
+EOI_TOKEN = '</img>'
+IMG_TOKEN = '<img_{:05d}>'
+
+
+class ContinuousLVLM(nn.Module):
+
+    def __init__(self, llm, input_resampler, output_resampler, lm_loss_scale=1.0, rec_loss_scale=1.0) -> None:
+        super().__init__()
+        self.llm = llm
+        self.input_resampler = input_resampler
+        self.output_resampler = output_resampler
+        self.lm_loss_scale = lm_loss_scale
+        self.rec_loss_scale = rec_loss_scale
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training forward (reference models.py:33-96) is outside the inference hot path")
+
+    @torch.no_grad()
+    def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,
+                 ids_cmp_mask=None, logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1,
+                 max_new_tokens=120, top_p=0.5, past_key_values=None, dtype=torch.float16, device='cuda',
+                 forced_tokens=None):
+        if logits_processor is None:
+            logits_processor = LogitsProcessorList()
+            logits_processor.append(
+                AutoImageTokenGenerationProcessor(tokenizer=tokenizer, num_img_gen_tokens=num_img_gen_tokens))
+        if prompt is not None:
+            input_ids = tokenizer(prompt, return_tensors="pt").input_ids
+        if isinstance(input_ids, list):
+            input_ids = torch.tensor(input_ids)
+        embed = self.llm.get_input_embeddings()
+        dev = embed.weight.device
+        input_ids = input_ids.to(device=dev)
+        input_embeds = embed(input_ids)                                   # [1, S, H]   (:127)
+        bz, sq, dim = input_embeds.shape
+        assert bz == 1, "the story path is batch 1"
+        if image_embeds is not None:
+            assert embeds_cmp_mask is not None and ids_cmp_mask is not None
+            image_embeds_lm = self.input_resampler(image_embeds.to(dev))  # [Nimg, 64, H] (:133)
+            sel = image_embeds_lm[embeds_cmp_mask.to(dev)].reshape(-1, dim).contiguous()
+            idx = torch.nonzero(ids_cmp_mask[0].to(dev), as_tuple=False).flatten()
+            assert idx.numel() == sel.shape[0], "ids_cmp_mask / embeds_cmp_mask disagree"
+            ops.scatter_rows_(input_embeds.view(-1, dim), idx, sel)       # (:135)
+
+        output = self.llm.generate(input_ids=input_ids, inputs_embeds=input_embeds, output_hidden_states=True,
+                                   return_dict_in_generate=True, logits_processor=logits_processor,
+                                   past_key_values=past_key_values, max_new_tokens=max_new_tokens,
+                                   temperature=temperature, num_beams=num_beams, top_p=top_p, do_sample=False,
+                                   forced_tokens=forced_tokens)
+        output_past_key_values = self.llm.past_key_values
+        generate_ids = output.sequences[0][input_ids.shape[1]:]
+        boi_token_id = tokenizer.encode(BOI_TOKEN, add_special_tokens=False)[0]
+        eoi_token_id = tokenizer.encode(EOI_TOKEN, add_special_tokens=False)[0]
+
+        last_hidden_states = torch.cat([hs[-1] for hs in output.hidden_states], dim=1)   # (:182)
+        if past_key_values is None:
+            last_hidden_states = last_hidden_states[0, input_ids.shape[1]:, :]
+            eoi_indices = torch.where(generate_ids == eoi_token_id)[0].tolist()
+        else:
+            last_hidden_states = last_hidden_states[0, :, :]
+            hidden_len = last_hidden_states.shape[0]
+            eoi_indices = torch.where(output.sequences[0][-hidden_len:] == eoi_token_id)[0].tolist()
+
+        num_gen_imgs = 1 if len(eoi_indices) > 0 else 0
+        has_img_output = num_gen_imgs > 0
+        if has_img_output:
+            e = eoi_indices[-1]
+            img_gen_feats = last_hidden_states[e - num_img_gen_tokens:e].unsqueeze(0).contiguous()  # (:197)
+            img_gen_feat = self.output_resampler(img_gen_feats)                                     # (:205)
+        else:
+            img_gen_feat = None
+        generate_text = tokenizer.decode(generate_ids, skip_special_tokens=False)
+        return {
+            'text': generate_text,
+            'generate_ids': generate_ids,
+            'has_img_output': has_img_output,
+            'img_gen_feat': img_gen_feat,
+            'num_gen_imgs': num_gen_imgs,
+            'attn_weights': (),
+            'past_key_values': output_past_key_values
+        }
+
+    @classmethod
+    def from_pretrained(cls, llm, input_resampler, output_resampler, pretrained_model_path=None, **kwargs):
+        model = cls(llm=llm, input_resampler=input_resampler, output_resampler=output_resampler, **kwargs)
+        if pretrained_model_path is not None:
+            ckpt = torch.load(pretrained_model_path, map_location='cpu')
+            missing, unexpected = model.load_state_dict(ckpt, strict=False)
+            print('agent model, missing keys: ', len(missing), 'unexpected keys:', len(unexpected))
+        return model

@@ -1,0 +1,224 @@
+"""GPU parity of the native engines (LLaMA prefill / continuation / hipGraph decode, Resampler,
+ViT) and of the reference-API mirror (ContinuousLVLM.generate) against the committed golden
+vectors, which were produced by the REAL reference modules (oracle/make_golden.py).
+
+fp32 is the "matches the reference CPU path" gate: logits / hidden states / regressed image
+features within 1e-4 relative (north-star tolerance: 1e-3 on img_gen_feat).  bf16 is checked
+against the reference's own bf16 CPU run: within 2e-2 relative (one-ulp rounding flips
+accumulate through the layers; LoRA-free weights here)."""
+import pytest
+import torch
+
+import seedstory_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _img_ids(meta):
+    lo, hi = meta["IMG_IDS"]
+    return list(range(lo, hi + 1))
+
+
+def _engine(meta, dtype, **kw):
+    from seedstory.llama import LlamaEngine
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
+    eng = LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"],
+                      vocab=d["vocab"], dtype=dtype, device=DEV, cache_cap=256, max_new=128, max_prefill_rows=64,
+                      img_ids=_img_ids(meta), **kw)
+    return eng, wd
+
+
+@pytest.mark.parametrize("dtype,tag,tol", [(torch.float32, "llama_f32", 1e-4), (torch.bfloat16, "llama_bf16", 2e-2)])
+def test_llama_prefill_continuation_decode(golden, dtype, tag, tol):
+    g, meta = golden
+    eng, wd = _engine(meta, dtype)
+    emb = wd["model.embed_tokens.weight"]
+    hid = eng.prefill(emb[g[tag + ".ids"][0]], want_hidden=True)
+    assert eng.lengths() == (37, 37)
+    assert rel(hid, g[tag + ".prefill_hidden"][0]) < tol
+    assert rel(eng.logits, g[tag + ".prefill_logits"][0, -1]) < tol
+    pkv = eng.past_key_values()
+    assert pkv[0][0].shape == (1, 2, 37, 128)
+    assert rel(pkv[0][0], g[tag + ".prefill_k0"]) < tol
+    assert rel(pkv[1][1], g[tag + ".prefill_v1"]) < tol
+    # continuation: 9 new rows against the cached prefix (bottom-right causal mask)
+    hid2 = eng.prefill(emb[g[tag + ".ids2"][0]], want_hidden=True)
+    assert eng.lengths() == (46, 46)
+    assert rel(hid2, g[tag + ".cont_hidden"][0]) < tol
+    assert rel(eng.logits, g[tag + ".cont_logits"][0, -1]) < tol
+    # single-token decode through the captured graph: force the golden token id
+    tok = int(g[tag + ".ids3"][0, 0])
+    n = eng.generate(2, last_prompt_id=5, forced=[tok, 3])
+    assert n == 2 and eng.gen_ids[:2].tolist() == [tok, 3]
+    assert rel(eng.hidden_rows[0], g[tag + ".decode_hidden"][0, 0]) < tol
+    assert eng.lengths() == (47, 47)
+
+
+def test_llama_graph_equals_eager(golden):
+    from seedstory import _lib
+    g, meta = golden
+    outs = []
+    for use_graph in (1, 0):
+        _lib.set_tuning("llama_graph", use_graph)
+        try:
+            eng, wd = _engine(meta, torch.bfloat16)
+            eng.prefill(wd["model.embed_tokens.weight"][g["llama_bf16.ids"][0]])
+            n = eng.generate(20, last_prompt_id=7)
+            outs.append((n, eng.gen_ids[:n].tolist(), eng.hidden_rows[:n - 1].clone()))
+        finally:
+            _lib.set_tuning("llama_graph", 1)
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
+def test_llama_lora_merge(golden):
+    """LoRA factors present: engine (merged once, fp32) vs the oracle's unmerged peft formula."""
+    g, meta = golden
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(12, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], lora_r=16)
+    from seedstory.llama import LlamaEngine
+    eng = LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"],
+                      vocab=d["vocab"], dtype=torch.float32, device=DEV, cache_cap=128, max_new=16,
+                      max_prefill_rows=64, img_ids=_img_ids(meta), lora_scaling=2.0)
+    ids = synth.randint(5, (1, 21), 3, 250)
+    emb = wd["model.embed_tokens.weight"][ids]
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    lg, hid, _ = O.llama_forward(wd, dims, emb, torch.arange(21).unsqueeze(0))
+    h = eng.prefill(emb[0], want_hidden=True)
+    assert rel(h, hid[0]) < 1e-4
+    assert rel(eng.logits, lg[0, -1]) < 1e-4
+
+
+def test_kv_truncate_and_sink_gather(golden):
+    """vis_george_sink.py:243 (truncate) and :266-295 (sink re-pack) on the slab."""
+    g, meta = golden
+    eng, wd = _engine(meta, torch.float32)
+    emb = wd["model.embed_tokens.weight"]
+    eng.prefill(emb[g["llama_f32.ids"][0]])
+    k_before = eng.k_cache[:, :, :37].clone()
+    keep, new_sink = O.sink_evict_indices(37, boi=10, eoi=27, sink_len=0, first=True)
+    eng.kv_gather(keep)
+    assert eng.lengths()[0] == len(keep)
+    assert torch.equal(eng.k_cache[:, :, :len(keep)].cpu(), k_before[:, :, keep].cpu())
+    eng.set_lengths(20, 20)
+    assert eng.past_key_values()[0][0].shape[2] == 20
+
+
+def test_resamplers(golden):
+    from src.models.qwen_visual import Resampler
+    g, meta = golden
+    for tag, key, seed in (("res_in", "RES_IN", 21), ("res_out", "RES_OUT", 22)):
+        c = meta[key]
+        wd = synth.resampler_weights(seed, "", c["grid"], c["embed"])
+        m = Resampler(grid_size=c["grid"], embed_dim=c["embed"], num_heads=c["heads"], kv_dim=c["embed"])
+        missing, unexpected = m.load_state_dict(wd, strict=False)
+        assert not missing and not unexpected
+        m = m.to(DEV)
+        y = m(g[tag + ".x"].to(DEV))
+        assert rel(y, g[tag + ".y"]) < 1e-4
+        yb = m.to(torch.bfloat16)(g[tag + ".x"].to(DEV, torch.bfloat16))
+        assert rel(yb, g[tag + ".y"]) < 2e-2
+
+
+def test_vit(golden):
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    g, meta = golden
+    c = meta["VIT"]
+    wd = synth.vit_weights(31, c["width"], c["layers"], c["heads"], c["mlp_width"], c["patch"], c["out_dim"],
+                           c["n_queries"])
+    m = VisionTransformerWithAttnPool(image_size=c["image"], patch_size=c["patch"], width=c["width"],
+                                      layers=c["layers"], heads=c["heads"], mlp_ratio=c["mlp_width"] / c["width"],
+                                      n_queries=c["n_queries"], output_dim=c["out_dim"])
+    missing, unexpected = m.load_state_dict(wd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    m = m.to(DEV)
+    y = m(g["vit.x"].to(DEV))
+    assert rel(y, g["vit.y"]) < 1e-4
+    yb = m.to(torch.bfloat16)(g["vit.x"].to(DEV))
+    assert rel(yb, g["vit.y"]) < 3e-2
+
+
+class _Tok:
+    def __init__(self, ids):
+        self.ids = ids
+
+    def encode(self, s, add_special_tokens=False):
+        if s == "<img>":
+            return [self.ids[0]]
+        if s == "</img>":
+            return [self.ids[-1]]
+        return list(self.ids)
+
+    def decode(self, ids, skip_special_tokens=False):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def test_continuous_lvlm_generate_matches_reference(golden):
+    """End to end through the reference API surface: ContinuousLVLM.generate -> img_gen_feat."""
+    from src.models.qwen_visual import Resampler
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    from src.models_clm.models import ContinuousLVLM
+    g, meta = golden
+    d = meta["LLAMA"]
+    cfg = LlamaConfig(hidden_size=d["hidden"], intermediate_size=d["inter"], num_hidden_layers=d["n_layers"],
+                      num_attention_heads=d["n_heads"], vocab_size=d["vocab"])
+    llm = LlamaForCausalLM(cfg)
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    missing, unexpected = llm.load_state_dict(wd, strict=False)
+    assert not missing and not unexpected
+    llm.cache_cap, llm.max_new, llm.max_prefill_rows = 256, 128, 64
+    llm.use_kv_cache_head = False
+    rin = Resampler(grid_size=meta["RES_IN"]["grid"], embed_dim=256, num_heads=2, kv_dim=256)
+    rin.load_state_dict(synth.resampler_weights(21, "", meta["RES_IN"]["grid"], 256))
+    rout = Resampler(grid_size=meta["RES_OUT"]["grid"], embed_dim=256, num_heads=2, kv_dim=256)
+    rout.load_state_dict(synth.resampler_weights(22, "", meta["RES_OUT"]["grid"], 256))
+    agent = ContinuousLVLM(llm, rin, rout).eval().to(DEV)
+    input_ids = g["gen.input_ids"]
+    n_in = meta["RES_IN"]["grid"] ** 2
+    mask = torch.zeros_like(input_ids, dtype=torch.bool)
+    mask[0, 14:14 + n_in] = True
+    out = agent.generate(tokenizer=_Tok(_img_ids(meta)), input_ids=input_ids, image_embeds=g["gen.image_embeds"].to(DEV),
+                         embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask, max_new_tokens=90,
+                         num_img_gen_tokens=64, forced_tokens=g["gen.forced"].tolist())
+    assert out["generate_ids"].tolist() == g["gen.generate_ids"].tolist()
+    assert out["has_img_output"] and out["num_gen_imgs"] == 1
+    r = rel(out["img_gen_feat"], g["gen.img_gen_feat"])
+    assert r < 1e-4, r  # north-star gate is 1e-3 relative on the regressed image feature
+    pkv = out["past_key_values"]
+    assert len(pkv) == d["n_layers"] and pkv[0][0].shape[2] == input_ids.shape[1] + 90 - 1
+
+
+def test_full_width_layer_properties():
+    """BASELINE full sizes (hidden 4096 / inter 11008 / 32 heads), one layer: size-independent
+    properties — (a) prefill-then-decode == prefill of the longer sequence (KV-cache consistency),
+    (b) the decode graph is deterministic across replays."""
+    from seedstory.llama import LlamaEngine
+    torch.manual_seed(0)
+    H, I, V = 4096, 11008, 32066
+    wd = synth.llama_weights(3, H, 32, 1, I, 1024, dtype=torch.bfloat16)
+    kw = dict(hidden=H, n_heads=32, n_layers=1, inter=I, vocab=1024, dtype=torch.bfloat16, device=DEV, cache_cap=512,
+              max_new=32, max_prefill_rows=256, img_ids=list(range(900, 966)))
+    emb = wd["model.embed_tokens.weight"]
+    ids = synth.randint(9, (120,), 3, 800)
+    a = LlamaEngine(wd, **kw)
+    ha = a.prefill(emb[ids], want_hidden=True)
+    b = LlamaEngine(wd, **kw)
+    b.prefill(emb[ids[:100]])
+    n = b.generate(21, last_prompt_id=int(ids[99]), forced=ids[100:].tolist() + [5])
+    assert n == 21
+    # rows 100..119 of the long prefill == decode rows 0..19 (same inputs, cached prefix)
+    r = rel(b.hidden_rows[:20], ha[100:120])
+    assert r < 2e-2, r
+    assert rel(b.k_cache[0, :, :120], a.k_cache[0, :, :120]) < 1e-2
+    c = LlamaEngine(wd, **kw)
+    c.prefill(emb[ids[:100]])
+    c.generate(21, last_prompt_id=int(ids[99]), forced=ids[100:].tolist() + [5])
+    assert torch.equal(c.hidden_rows[:20], b.hidden_rows[:20])

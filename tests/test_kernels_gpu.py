@@ -1,0 +1,287 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI (seedstory.ops -> ctypes ->
+libseedstory_hip.so) and checked against the CPU oracle (oracle/seedstory_oracle.py) or an fp32
+torch-CPU evaluation of the same formula on the same (already rounded) inputs.
+
+Tolerances (stated per test): fp32 mode is the "matches the reference CPU path" gate
+(<= 1e-5 relative Frobenius unless noted); bf16 mode rounds where the reference rounds, so
+element-wise kernels are bit-exact up to 1 bf16 ulp on a <=0.2 % minority of elements (fp32
+reduction-order differences in the statistic), contractions are within bf16 rounding of the fp32
+result."""
+import math
+
+import pytest
+import torch
+
+import seedstory_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (no CPU fallback exists)")
+    from seedstory import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def ulp_report(a, b):
+    """bf16 tensors: fraction of elements that differ and max difference in units of bf16 ulp of b."""
+    a, b = a.float().cpu(), b.float().cpu()
+    diff = (a - b).abs()
+    ulp = torch.maximum(b.abs(), torch.tensor(1e-30)) * 2.0 ** -7
+    return float((diff > 0).float().mean()), float((diff / ulp).max())
+
+
+def dev(t, dtype=None):
+    return t.to(device=DEV, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 256), (37, 4096), (3, 1664), (2, 11008)])
+def test_rmsnorm(ops, rows, cols):
+    x32 = synth.normal_like(1, (rows, cols), 1.5)
+    w32 = synth.normal_like(2, (cols,), 0.1, 1.0)
+    y = ops.rmsnorm(dev(x32), dev(w32), 1e-5)
+    assert rel(y, O.rmsnorm(x32, w32, 1e-5)) < 1e-6
+    xb, wb = x32.bfloat16(), w32.bfloat16()
+    yb = ops.rmsnorm(dev(xb), dev(wb), 1e-5)
+    frac, mx = ulp_report(yb, O.rmsnorm(xb, wb, 1e-5))
+    assert frac < 2e-3 and mx <= 1.01, (frac, mx)
+
+
+@pytest.mark.parametrize("rows,cols,eps", [(7, 256, 1e-5), (64, 4096, 1e-5), (33, 1664, 1e-6), (5, 1024, 1e-5)])
+def test_layernorm(ops, rows, cols, eps):
+    x32 = synth.normal_like(3, (rows, cols), 2.0, 0.3)
+    w32 = synth.normal_like(4, (cols,), 0.1, 1.0)
+    b32 = synth.normal_like(5, (cols,), 0.1)
+    y = ops.layernorm(dev(x32), dev(w32), dev(b32), eps)
+    assert rel(y, O.layernorm(x32, w32, b32, eps)) < 1e-6
+    xb, wb, bb = x32.bfloat16(), w32.bfloat16(), b32.bfloat16()
+    yb = ops.layernorm(dev(xb), dev(wb), dev(bb), eps)
+    frac, mx = ulp_report(yb, O.layernorm(xb, wb, bb, eps))
+    assert frac < 5e-3 and mx <= 1.01, (frac, mx)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_kv_append(ops, dtype):
+    H, hd, M, cap = 3, 128, 6, 32
+    E = H * hd
+    qkv = synth.normal_like(6, (M, 3 * E), 1.0, dtype=dtype)
+    pos = torch.tensor([3, 9, 10, 40, 63, 4000])
+    cos, sin = O.rope_tables(hd, 4096, dtype)
+    kc = torch.zeros(H, cap, hd, dtype=dtype, device=DEV)
+    vc = torch.zeros(H, cap, hd, dtype=dtype, device=DEV)
+    q = ops.rope_kv_append(dev(qkv), kc, vc, dev(cos), dev(sin), H, kv_start=5, pos_ids=pos)
+    qr = qkv[:, :E].view(1, M, H, hd).transpose(1, 2)
+    kr = qkv[:, E:2 * E].view(1, M, H, hd).transpose(1, 2)
+    vr = qkv[:, 2 * E:].view(M, H, hd).transpose(0, 1)
+    q_ref = O.apply_rope(qr, cos, sin, pos.unsqueeze(0))[0].transpose(0, 1).reshape(M, E)
+    k_ref = O.apply_rope(kr, cos, sin, pos.unsqueeze(0))[0]
+    assert torch.equal(q.cpu(), q_ref), "q rope must be bit-exact (same roundings as the reference)"
+    assert torch.equal(kc[:, 5:5 + M].cpu(), k_ref)
+    assert torch.equal(vc[:, 5:5 + M].cpu(), vr)
+    assert float(kc[:, :5].abs().sum()) == 0 and float(kc[:, 5 + M:].abs().sum()) == 0
+    # contiguous positions path (pos_start)
+    q2 = ops.rope_kv_append(dev(qkv), kc, vc, dev(cos), dev(sin), H, kv_start=0, pos_start=7)
+    q2_ref = O.apply_rope(qr, cos, sin, torch.arange(7, 7 + M).unsqueeze(0))[0].transpose(0, 1).reshape(M, E)
+    assert torch.equal(q2.cpu(), q2_ref)
+
+
+GEMV_SHAPES = [(512, 256), (100, 512), (4096, 4096), (4096, 11008), (1000, 1664), (33, 8)]
+
+
+@pytest.mark.parametrize("N,K", GEMV_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemv_plain_and_epilogues(ops, N, K, dtype):
+    w = synth.normal_like(7, (N, K), 0.05, dtype=dtype)
+    x = synth.normal_like(8, (K,), 1.0, dtype=dtype)
+    res = synth.normal_like(9, (N,), 1.0, dtype=dtype)
+    bias = synth.normal_like(10, (N,), 0.5, dtype=dtype)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    ref = w.float() @ x.float()
+    y = ops.gemv(dev(w), dev(x))
+    assert rel(y, ref.to(dtype)) < tol
+    y = ops.gemv(dev(w), dev(x), bias=dev(bias), residual=dev(res))
+    ref2 = ((ref + bias.float()).to(dtype) + res).to(dtype)
+    assert rel(y, ref2) < tol
+    # fused RMSNorm prologue
+    nw = synth.normal_like(11, (K,), 0.1, 1.0, dtype=dtype)
+    xn = O.rmsnorm(x, nw, 1e-5)
+    y = ops.gemv(dev(w), dev(x), norm_w=dev(nw), eps=1e-5)
+    assert rel(y, (w.float() @ xn.float()).to(dtype)) < tol
+
+
+@pytest.mark.parametrize("I,K", [(256, 256), (512, 4096), (11008, 4096)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemv_silu_mul(ops, I, K, dtype):
+    w = synth.normal_like(12, (2 * I, K), 0.05, dtype=dtype)
+    x = synth.normal_like(13, (K,), 1.0, dtype=dtype)
+    gu = (w.float() @ x.float()).to(dtype)
+    ref = torch.nn.functional.silu(gu[:I]) * gu[I:]
+    y = ops.gemv(dev(w), dev(x), silu_mul=True)
+    assert rel(y, ref) < (1e-5 if dtype == torch.float32 else 6e-3)
+
+
+GEMM_SHAPES = [(1, 64, 64), (37, 100, 256), (65, 4096, 4096), (114, 1000, 4096), (343, 768, 512),
+               (130, 4992, 1664), (256, 1664, 608), (300, 256, 8192), (1024, 512, 1664)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm(ops, M, N, K, dtype):
+    a = synth.normal_like(14, (M, K), 1.0, dtype=dtype)
+    w = synth.normal_like(15, (N, K), 0.05, dtype=dtype)
+    bias = synth.normal_like(16, (N,), 0.5, dtype=dtype)
+    res = synth.normal_like(17, (M, N), 1.0, dtype=dtype)
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    ref = a.float() @ w.float().t()
+    y = ops.gemm(dev(a), dev(w))
+    assert rel(y, ref) < tol, "plain"
+    y = ops.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res))
+    assert rel(y, ((ref + bias.float()).to(dtype) + res).float()) < tol, "bias+residual"
+    y = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True)
+    assert rel(y, torch.nn.functional.gelu((ref + bias.float()).to(dtype))) < tol * 1.5, "bias+gelu"
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_every_tile_config(ops, cfg):
+    from seedstory import _lib
+    a = synth.normal_like(18, (200, 512), 1.0, dtype=torch.bfloat16)
+    w = synth.normal_like(19, (300, 512), 0.05, dtype=torch.bfloat16)
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        y = ops.gemm(dev(a), dev(w))
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(y, a.float() @ w.float().t()) < 4e-3
+
+
+def attn_ref(q, k, v, n_heads, scale, causal_br):
+    """fp32 softmax attention on [B, L, E] with packed heads."""
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    hd = E // n_heads
+    qh = q.float().view(B, Lq, n_heads, hd).transpose(1, 2)
+    kh = k.float().view(k.shape[0], Lk, n_heads, hd).transpose(1, 2)
+    vh = v.float().view(v.shape[0], Lk, n_heads, hd).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    if causal_br:
+        allow = torch.ones(Lq, Lk, dtype=torch.bool).tril(diagonal=Lk - Lq)
+        s = s.masked_fill(~allow, float("-inf"))
+    o = torch.matmul(torch.softmax(s, -1), vh)
+    return o.transpose(1, 2).reshape(B, Lq, E)
+
+
+ATTN_CASES = [  # B, heads, hd, Lq, Lk, causal
+    (1, 2, 128, 37, 37, True), (1, 2, 128, 9, 46, True), (1, 3, 128, 343, 343, True), (1, 2, 128, 65, 400, True),
+    (1, 2, 128, 1, 70, True), (2, 2, 104, 16, 16, False), (1, 16, 104, 1024, 1024, False), (3, 2, 128, 16, 64, False),
+    (2, 4, 64, 8, 24, False), (2, 16, 64, 64, 320, False), (1, 2, 128, 256, 64, False)]
+
+
+@pytest.mark.parametrize("B,H,hd,Lq,Lk,causal", ATTN_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flash_attention(ops, B, H, hd, Lq, Lk, causal, dtype):
+    E = H * hd
+    q = synth.normal_like(20, (B, Lq, E), 1.0, dtype=dtype)
+    k = synth.normal_like(21, (B, Lk, E), 1.0, dtype=dtype)
+    v = synth.normal_like(22, (B, Lk, E), 1.0, dtype=dtype)
+    scale = 1.0 / math.sqrt(hd)
+    o = ops.attention(dev(q), dev(k), dev(v), H, scale, causal)
+    ref = attn_ref(q, k, v, H, scale, causal)
+    assert rel(o, ref) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_flash_attention_softmax_rescale_branch(ops):
+    """Online-softmax correctness when the running max jumps late: spike one key in the last tile."""
+    H, hd, Lq, Lk = 1, 128, 32, 200
+    q = synth.normal_like(23, (1, Lq, hd), 1.0)
+    k = synth.normal_like(24, (1, Lk, hd), 1.0)
+    v = synth.normal_like(25, (1, Lk, hd), 1.0)
+    k[0, 190] = q[0, 5] * 3.0
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1e-2)):
+        o = ops.attention(dev(q, dtype), dev(k, dtype), dev(v, dtype), H, 1.0 / math.sqrt(hd), False)
+        assert rel(o, attn_ref(q.to(dtype), k.to(dtype), v.to(dtype), H, 1.0 / math.sqrt(hd), False)) < tol
+
+
+@pytest.mark.parametrize("kv_len", [1, 17, 64, 500, 1100])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_decode(ops, kv_len, dtype):
+    H, hd, cap = 4, 128, 1200
+    q = synth.normal_like(26, (H * hd,), 1.0, dtype=dtype)
+    kc = synth.normal_like(27, (H, cap, hd), 1.0, dtype=dtype)
+    vc = synth.normal_like(28, (H, cap, hd), 1.0, dtype=dtype)
+    n = torch.tensor([kv_len], dtype=torch.int32, device=DEV)
+    o = ops.attn_decode(dev(q), dev(kc), dev(vc), n)
+    qh = q.float().view(H, 1, hd)
+    s = torch.matmul(qh, kc[:, :kv_len].float().transpose(-1, -2)) / math.sqrt(hd)
+    ref = torch.matmul(torch.softmax(s, -1), vc[:, :kv_len].float()).reshape(H * hd)
+    assert rel(o, ref) < (1e-5 if dtype == torch.float32 else 4e-3)
+
+
+def test_attention_cache_matches_decode(ops):
+    """q_len=1 through the flash kernel == split-KV decode kernel (same cache planes)."""
+    H, hd, cap, kv = 2, 128, 300, 257
+    dtype = torch.bfloat16
+    q = dev(synth.normal_like(29, (1, H * hd), 1.0, dtype=dtype))
+    kc = dev(synth.normal_like(30, (H, cap, hd), 1.0, dtype=dtype))
+    vc = dev(synth.normal_like(31, (H, cap, hd), 1.0, dtype=dtype))
+    a = ops.attention_cache(q, kc, vc, kv, causal_br=True)
+    b = ops.attn_decode(q[0].contiguous(), kc, vc, torch.tensor([kv], dtype=torch.int32, device=DEV))
+    assert rel(a[0], b) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_imgproc_argmax(ops, dtype, golden):
+    g, meta = golden
+    lo, hi = meta["IMG_IDS"]
+    ids = list(range(lo, hi + 1))
+    V = meta["LLAMA"]["vocab"]
+    for i, last in enumerate([17, ids[0], ids[5], ids[64], ids[65], 2]):
+        sc = synth.normal_like(300 + i, (1, V), 2.0, dtype=dtype)[0]
+        ref = O.image_token_logits_processor(last, sc.clone(), ids)
+        d = dev(sc)
+        tok = ops.imgproc_argmax(d, last, ids)
+        assert torch.equal(d.cpu(), ref), "processor must edit the logits exactly like the reference"
+        assert int(tok.item()) == int(torch.argmax(ref))
+    # ties resolve to the first index (torch.argmax on CPU)
+    t = torch.zeros(V, dtype=dtype)
+    t[[40, 7, 99]] = 5.0
+    assert int(ops.imgproc_argmax(dev(t), 3, ids).item()) == 7
+    # a large vocabulary (LLaMA + 66 image tokens)
+    big = synth.normal_like(77, (32066,), 3.0, dtype=dtype)
+    ids2 = list(range(32000, 32066))
+    ref = O.image_token_logits_processor(11, big.clone(), ids2)
+    assert int(ops.imgproc_argmax(dev(big), 11, ids2).item()) == int(torch.argmax(ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_elementwise(ops, dtype):
+    gu = synth.normal_like(32, (9, 2 * 512), 1.5, dtype=dtype)
+    ref = torch.nn.functional.silu(gu[:, :512]) * gu[:, 512:]
+    assert rel(ops.silu_mul(dev(gu)), ref) < (1e-6 if dtype == torch.float32 else 3e-3)
+    x = synth.normal_like(33, (3, 16, 256), 1.0, dtype=dtype)
+    pz = synth.normal_like(34, (16, 256), 1.0, dtype=dtype)
+    assert torch.equal(ops.add_bcast(dev(x), dev(pz)).cpu(), x + pz)
+    table = synth.normal_like(35, (50, 256), 1.0, dtype=dtype)
+    ids = torch.tensor([3, 49, 0, 3, 17])
+    assert torch.equal(ops.gather_rows(dev(table), ids).cpu(), table[ids])
+    dst = dev(torch.zeros(20, 256, dtype=dtype))
+    src = synth.normal_like(36, (4, 256), 1.0, dtype=dtype)
+    ops.scatter_rows_(dst, torch.tensor([5, 6, 7, 19]), dev(src))
+    ref = torch.zeros(20, 256, dtype=dtype)
+    ref[[5, 6, 7, 19]] = src
+    assert torch.equal(dst.cpu(), ref)
+    img = synth.normal_like(37, (2, 3, 56, 56), 1.0, dtype=dtype)
+    col = ops.im2col_patch(dev(img), 14, 640).cpu()
+    ref = torch.nn.functional.unfold(img.float(), kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588)
+    assert torch.equal(col[:, :588].float(), ref) and float(col[:, 588:].abs().sum()) == 0
+    xl = synth.normal_like(38, (2, 16, 256), 1.0, dtype=dtype)
+    assert rel(ops.l2normalize_dim1(dev(xl)), torch.nn.functional.normalize(xl.float())) < (1e-6 if dtype == torch.float32 else 4e-3)

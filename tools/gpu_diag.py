@@ -1,0 +1,174 @@
+"""GPU-box diagnostics: kernel micro-benchmarks + knob sweeps, written to gpurun_out/diag.json.
+Usage (on the GPU box): python tools/gpu_diag.py [gemv] [gemm] [attn] [decode]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "seed-story_amd"))
+import torch  # noqa: E402
+from seedstory import _lib, ops  # noqa: E402
+
+DEV = "cuda:0"
+OUT = {}
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters  # ms
+
+
+def bench_gemv():
+    res = []
+    shapes = [("qkv", 12288, 4096, {}), ("o", 4096, 4096, {}), ("gateup", 11008, 4096, {"silu_mul": True}),
+              ("down", 4096, 11008, {}), ("lm_head", 32066, 4096, {})]
+    # rotate over several weight copies so the 256 MiB Infinity Cache cannot serve the stream
+    for name, N, K, kw in shapes:
+        rows = N * 2 if kw.get("silu_mul") else N
+        ncopy = max(2, int(600e6 // (rows * K * 2)) + 1)
+        ws = [torch.randn(rows, K, device=DEV, dtype=torch.bfloat16) * 0.02 for _ in range(ncopy)]
+        x = torch.randn(K, device=DEV, dtype=torch.bfloat16)
+        nw = torch.ones(K, device=DEV, dtype=torch.bfloat16)
+        for gpw in (1, 2, 4, 8):
+            for nt in (1, 0):
+                _lib.set_tuning("gemv_groups_per_wave", gpw)
+                _lib.set_tuning("gemv_nt", nt)
+                st = {"i": 0}
+
+                def f():
+                    st["i"] += 1
+                    ops.gemv(ws[st["i"] % ncopy], x, norm_w=nw if name in ("qkv", "gateup") else None, eps=1e-5, **kw)
+                ms = timeit(f, iters=30)
+                gbs = rows * K * 2 / ms / 1e6
+                res.append(dict(name=name, N=N, K=K, gpw=gpw, nt=nt, ms=round(ms, 4), GBps=round(gbs, 1)))
+                print(res[-1], flush=True)
+        del ws
+    _lib.set_tuning("gemv_groups_per_wave", 2)
+    _lib.set_tuning("gemv_nt", 1)
+    OUT["gemv"] = res
+
+
+def bench_gemm():
+    res = []
+    shapes = [(343, 12288, 4096), (913, 12288, 4096), (913, 4096, 4096), (913, 22016, 4096), (913, 4096, 11008),
+              (65, 12288, 4096), (65, 22016, 4096), (114, 4096, 11008), (1024, 4992, 1664), (1024, 1664, 1664),
+              (1024, 8192, 1664), (1024, 1664, 8192), (256, 4096, 4096), (4096, 4096, 4096)]
+    for M, N, K in shapes:
+        a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+        w = torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        for cfg in (0, 1, 2, 3):
+            _lib.set_tuning("gemm_cfg", cfg)
+            ms = timeit(lambda: ops.gemm(a, w, out=out), iters=10)
+            res.append(dict(M=M, N=N, K=K, cfg=cfg, ms=round(ms, 4), TFLOPs=round(2.0 * M * N * K / ms / 1e9, 1),
+                            GBps=round((N * K + M * K + M * N) * 2 / ms / 1e6, 1)))
+            print(res[-1], flush=True)
+    _lib.set_tuning("gemm_cfg", 0)
+    OUT["gemm"] = res
+
+
+def bench_attn():
+    res = []
+    for (B, H, hd, Lq, Lk, causal) in [(1, 32, 128, 343, 343, True), (1, 32, 128, 913, 913, True),
+                                        (1, 32, 128, 65, 900, True), (1, 16, 104, 1024, 1024, False),
+                                        (8, 32, 128, 64, 256, False)]:
+        E = H * hd
+        q = torch.randn(B, Lq, E, device=DEV, dtype=torch.bfloat16)
+        k = torch.randn(B, Lk, E, device=DEV, dtype=torch.bfloat16)
+        v = torch.randn(B, Lk, E, device=DEV, dtype=torch.bfloat16)
+        ms = timeit(lambda: ops.attention(q, k, v, H, None, causal), iters=10)
+        fl = 4.0 * B * H * Lq * Lk * hd * (0.5 if causal and Lq == Lk else 1.0)
+        res.append(dict(B=B, H=H, hd=hd, Lq=Lq, Lk=Lk, causal=causal, ms=round(ms, 4), TFLOPs=round(fl / ms / 1e9, 1)))
+        print(res[-1], flush=True)
+    kc = torch.randn(32, 2048, 128, device=DEV, dtype=torch.bfloat16)
+    vc = torch.randn(32, 2048, 128, device=DEV, dtype=torch.bfloat16)
+    q = torch.randn(4096, device=DEV, dtype=torch.bfloat16)
+    for kv in (100, 500, 1000, 2000):
+        for ns in (4, 8, 16):
+            _lib.set_tuning("attn_decode_nsplit", ns)
+            n = torch.tensor([kv], dtype=torch.int32, device=DEV)
+            ms = timeit(lambda: ops.attn_decode(q, kc, vc, n), iters=20)
+            res.append(dict(decode_kv=kv, nsplit=ns, ms=round(ms, 4), GBps=round(2 * 32 * kv * 128 * 2 / ms / 1e6, 1)))
+            print(res[-1], flush=True)
+    _lib.set_tuning("attn_decode_nsplit", 8)
+    OUT["attn"] = res
+
+
+def make_7b_engine(n_layers=32, cache_cap=2048, max_new=512, max_rows=1024):
+    from seedstory.llama import LlamaEngine
+    H, I, V = 4096, 11008, 32066
+    dt = torch.bfloat16
+
+    def rnd(*s):
+        return torch.randn(*s, device=DEV, dtype=dt) * 0.02
+
+    layers = [(rnd(3 * H, H), rnd(H, H), rnd(2 * I, H), rnd(H, I), torch.ones(H, device=DEV, dtype=dt),
+               torch.ones(H, device=DEV, dtype=dt)) for _ in range(n_layers)]
+    return LlamaEngine.from_prebuilt(embed=rnd(V, H), lm_head=rnd(V, H), final_norm=torch.ones(H, device=DEV, dtype=dt),
+                                     layers=layers, hidden=H, n_heads=32, n_layers=n_layers, inter=I, vocab=V, dtype=dt,
+                                     device=DEV, cache_cap=cache_cap, max_new=max_new, max_prefill_rows=max_rows,
+                                     img_ids=list(range(32000, 32066)))
+
+
+def bench_decode():
+    res = {}
+    eng = make_7b_engine()
+    H = 4096
+    for S in (343, 913):
+        emb = torch.randn(S, H, device=DEV, dtype=torch.bfloat16) * 0.02
+        eng.reset()
+        eng.prefill(emb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.reset()
+        eng.prefill(emb)
+        torch.cuda.synchronize()
+        res["prefill_%d_ms" % S] = round((time.perf_counter() - t0) * 1e3, 3)
+        forced = torch.randint(3, 32000, (115,)).tolist()
+        eng.generate(8, 5, forced[:8])  # capture + warm
+        eng.set_lengths(S, S)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = eng.generate(115, 5, forced)
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        res["decode_115_at_%d_ms" % S] = round(dtm * 1e3, 3)
+        res["decode_tok_ms_at_%d" % S] = round(dtm * 1e3 / n, 4)
+        print(S, res, flush=True)
+        # continuation prefill of 65 rows against the cache
+        eng.set_lengths(S, S)
+        emb2 = torch.randn(65, H, device=DEV, dtype=torch.bfloat16) * 0.02
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prefill(emb2)
+        torch.cuda.synchronize()
+        res["continuation_65_at_%d_ms" % S] = round((time.perf_counter() - t0) * 1e3, 3)
+    eng.set_lengths(913, 913)
+    res["profile"] = eng.profile_decode(4)
+    p = res["profile"]
+    res["gemv_GBps_in_token"] = round(p["gemv_bytes"] / p["gemv_ms"] / 1e6, 1)
+    print(res, flush=True)
+    OUT["decode"] = res
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemv", "gemm", "attn", "decode"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    for w in which:
+        try:
+            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode}[w]()
+        except Exception as ex:  # keep going: one broken kernel must not hide the other numbers
+            import traceback
+            traceback.print_exc()
+            OUT[w + "_error"] = repr(ex)
+        with open(os.path.join(ROOT, "gpurun_out", "diag.json"), "w") as f:
+            json.dump(OUT, f, indent=1)
