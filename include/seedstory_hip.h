@@ -231,11 +231,14 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
 int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, const int32_t* host_forced,
                       int64_t n_forced, int64_t* host_n_generated, void* stream);
 
-/* Per-kernel-class device time of one decode token, measured with hipEvents around every
- * launch of an un-captured (eager) decode step, averaged over n_tokens:
- * out_ms[0]=gemv total, [1]=attention(+combine), [2]=rope/kv, [3]=norm+sampling+misc,
- * [4]=whole token; out_bytes[0] = weight bytes streamed by the GEMV launches of one token. */
-int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], double out_bytes[2],
+/* Per-kernel-class device time of one decode token, measured with a hipEvent pair around EVERY
+ * launch of un-captured (eager) decode steps on `stream`, averaged over n_tokens:
+ * out_ms[0] = sum over the K=hidden GEMV launches (qkv, o, gate|up per layer + lm_head:
+ *             ss::gemv_kernel), [1] = attention (+split merge), [2] = sum over the down-projection
+ *             GEMV launches (ss::gemv_ldsx_kernel), [3] = sampling + final norm, [4] = whole token;
+ * out_bytes[0] = weight bytes streamed by the class-0 launches of one token, [1] = their count,
+ * out_bytes[2] / [3] = the same for class 2. */
+int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], double out_bytes[4],
                             void* stream);
 
 /* ---------------------------------------------------------------------------------------

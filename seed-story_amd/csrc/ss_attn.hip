@@ -244,125 +244,231 @@ int attention_dev(const AttnArgs& a, int64_t batch, int dtype, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------------------------
-// (2) decode attention (q_len = 1), split-KV
+// (2) decode attention (q_len = 1), split-KV, with RoPE + KV append fused in
 // --------------------------------------------------------------------------------------------
-// partial record per (head, split): [m, l, o[hd]] fp32
+// grid (n_heads, nsplit), 256 threads.  Thread t works for key group kg = t / LPK (LPK = hd/V lanes
+// share one key, each holding V consecutive d) and streams keys kg, kg+NKG, ... of its block's
+// chunk with a PRIVATE online softmax (m, l, acc[V]) — no block-level barrier in the key loop; the
+// NKG groups are merged once through LDS.  All K/V packs of a 4-keys-per-thread sub-chunk are
+// issued before the first use (one HBM round trip per 4*NKG keys).
+//
+// Fused (engine path, qkv_raw != NULL): q and the NEW token's k are rotated here in the model dtype
+// exactly like rotate_half/apply_rotary_pos_emb (modeling_llama_xformer.py:158-173); the block that
+// owns position kv_len stores the rotated k and v into the cache (the torch.cat of :239-242) and
+// takes them from registers, so no other kernel (and no global read-after-write) is needed.
+// partial record per (head, split): [m, l, o[hd]] fp32; attn_combine_kernel merges the splits.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                          const T* __restrict__ vc, float* __restrict__ part,
-                                                          const int32_t* __restrict__ kv_len_dev, int kv_len_add,
-                                                          const int32_t* __restrict__ done_flag, int hd,
-                                                          int cache_cap, int nsplit, int chunk_cap, float scale) {
+__device__ __forceinline__ uint4 rope_pack(const T* row_h, const T* cos_t, const T* sin_t, int pos, int hd, int d0) {
+    // returns round(round(x*cos) + round(rot*sin)) for d in [d0, d0+V)
     constexpr int V = Tr<T>::kVec;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sc = reinterpret_cast<float*>(smem_raw);  // [chunk_cap] scores / probabilities
-    float* red = sc + chunk_cap;                     // [16]
-    float* osum = red + 16;                          // [4][hd]
-    if (done_flag && *done_flag) return;
-    const int h = blockIdx.x, sp = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int kv_len = *kv_len_dev + kv_len_add;
-    const int chunk = (kv_len + nsplit - 1) / nsplit;
-    const int k_lo = sp * chunk;
-    const int k_hi = min(kv_len, k_lo + chunk);
-    const int n = max(0, k_hi - k_lo);
-    const int LPK = hd / V;        // lanes per key
-    const int KPW = 64 / LPK;      // keys per wave per iteration
-    const int sub = lane / LPK, dl = lane % LPK;
-    float* rec = part + ((int64_t)h * nsplit + sp) * (hd + 2);
-
-    uint4 qv = ld16(q + (int64_t)h * hd + dl * V);
-    const T* kh = kc + (int64_t)h * cache_cap * hd;
-    const T* vh = vc + (int64_t)h * cache_cap * hd;
-
-    // ---- scores ------------------------------------------------------------------------------------
-    float lmax = -1e30f;
-    for (int i = wid * KPW + sub; i < n; i += 4 * KPW) {
-        const uint4 kk = ld16(kh + (int64_t)(k_lo + i) * hd + dl * V);
-        float d = dot_pack<T>(kk, qv, 0.f);
-        for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        d *= scale;
-        if (dl == 0) sc[i] = d;
-        lmax = fmaxf(lmax, d);
-    }
-    const float m = block_max(lmax, red);
-    // ---- probabilities (fp32, like the oracle's softmax) ------------------------------------------------
-    float ls = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const float p = expf(sc[i] - m);
-        sc[i] = p;
-        ls += p;
-    }
-    const float l = block_sum(ls, red);  // (contains the barriers that publish sc[])
-    // ---- PV ----------------------------------------------------------------------------------------
-    float acc[V];
+    const int half = hd >> 1;
+    float x[V], xp[V], c[V], sn[V], o[V];
+    unpack<T>(ld16(row_h + d0), x);
+    unpack<T>(ld16(row_h + (d0 < half ? d0 + half : d0 - half)), xp);
+    unpack<T>(ld16(cos_t + (int64_t)pos * hd + d0), c);
+    unpack<T>(ld16(sin_t + (int64_t)pos * hd + d0), sn);
+    const float sign = d0 < half ? -1.f : 1.f;
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    for (int i = wid * KPW + sub; i < n; i += 4 * KPW) {
-        float vf[V];
-        unpack<T>(ld16(vh + (int64_t)(k_lo + i) * hd + dl * V), vf);
-        const float p = sc[i];
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < V; ++j)
-        for (int o = LPK; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
-    if (sub == 0) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) osum[wid * hd + dl * V + j] = acc[j];
-    }
-    __syncthreads();
-    if (tid < hd) rec[2 + tid] = osum[tid] + osum[hd + tid] + osum[2 * hd + tid] + osum[3 * hd + tid];
-    if (tid == 0) { rec[0] = n > 0 ? m : -1e30f; rec[1] = n > 0 ? l : 0.f; }
+    for (int j = 0; j < V; ++j) o[j] = Tr<T>::rnd(Tr<T>::rnd(x[j] * c[j]) + Tr<T>::rnd(sign * xp[j] * sn[j]));
+    return pack<T>(o);
 }
 
+struct DecodeArgs {
+    const void* q;        // rotated q [n_heads*hd]            (plain mode)
+    const void* qkv_raw;  // [3*n_heads*hd] pre-RoPE q|k|v      (fused mode) or NULL
+    void *kc, *vc;        // cache planes [n_heads, cap, hd]
+    const void *cos_t, *sin_t;
+    float* part;
+    const int32_t* kv_len_dev;  // entries already in the cache
+    const int32_t* pos_dev;     // rope position of the new token (fused mode)
+    const int32_t* done_flag;
+    int hd, n_heads, cap, nsplit;
+    float scale;
+};
+
 template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int KPT = 4;  // keys per thread per sub-chunk
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);  // [NKG][hd + 2]
+    if (a.done_flag && *a.done_flag) return;
+    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const int hd = a.hd;
+    const int LPK = hd / V, NKG = 256 / LPK;
+    const int kg = tid / LPK, dl = tid % LPK, d0 = dl * V;
+    const bool fused = a.qkv_raw != nullptr;
+    const int n_old = *a.kv_len_dev;
+    const int kv_len = n_old + (fused ? 1 : 0);
+    const int chunk = (kv_len + a.nsplit - 1) / a.nsplit;
+    const int k_lo = sp * chunk;
+    const int k_hi = min(kv_len, k_lo + chunk);
+    const T* kh = (const T*)a.kc + (int64_t)h * a.cap * hd;
+    const T* vh = (const T*)a.vc + (int64_t)h * a.cap * hd;
+    const int E = a.n_heads * hd;
+
+    // The first sub-chunk's K/V packs are requested before anything else: their HBM/L2 round trip
+    // overlaps the q/k RoPE arithmetic below (which has its own dependent loads: qkv row, cos/sin).
+    auto load_kv = [&](int base, uint4 (&kk)[KPT], uint4 (&vv)[KPT]) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int key = base + i * NKG;
+            if (key < k_hi && !(fused && key == n_old)) {
+                kk[i] = ld16(kh + (int64_t)key * hd + d0);
+                vv[i] = ld16(vh + (int64_t)key * hd + d0);
+            } else {
+                kk[i] = make_uint4(0, 0, 0, 0);
+                vv[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    uint4 kk[KPT], vv[KPT];
+    int base = k_lo + kg;
+    if (base < k_hi) load_kv(base, kk, vv);
+
+    uint4 qv, knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
+    if (fused) {
+        const T* raw = (const T*)a.qkv_raw;
+        const int pos = *a.pos_dev;
+        qv = rope_pack<T>(raw + (int64_t)h * hd, (const T*)a.cos_t, (const T*)a.sin_t, pos, hd, d0);
+        if (n_old >= k_lo && n_old < k_hi) {  // this block owns the new position
+            knew = rope_pack<T>(raw + E + (int64_t)h * hd, (const T*)a.cos_t, (const T*)a.sin_t, pos, hd, d0);
+            vnew = ld16(raw + 2 * E + (int64_t)h * hd + d0);
+            if (kg == (n_old - k_lo) % NKG && n_old < a.cap) {
+                st16((T*)a.kc + ((int64_t)h * a.cap + n_old) * hd + d0, knew);
+                st16((T*)a.vc + ((int64_t)h * a.cap + n_old) * hd + d0, vnew);
+            }
+        }
+    } else {
+        qv = ld16((const T*)a.q + (int64_t)h * hd + d0);
+    }
+
+    float m = -1e30f, l = 0.f, acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    while (base < k_hi) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int key = base + i * NKG;
+            const bool is_new = fused && key == n_old;
+            const uint4 kx = is_new ? knew : kk[i];
+            const uint4 vx = is_new ? vnew : vv[i];
+            float s = dot_pack<T>(kx, qv, 0.f);
+            for (int o = LPK >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (key < k_hi) {  // uniform within the LPK-lane key group
+                s *= a.scale;
+                const float mn = fmaxf(m, s);
+                const float al = expf(m - mn), p = expf(s - mn);
+                float vf[V];
+                unpack<T>(vx, vf);
+                l = l * al + p;
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(p, vf[j], acc[j] * al);
+                m = mn;
+            }
+        }
+        base += NKG * KPT;
+        if (base < k_hi) load_kv(base, kk, vv);
+    }
+    // ---- merge the NKG private softmaxes --------------------------------------------------------
+    float* mine = sm + kg * (hd + 2);
+    if (dl == 0) { mine[0] = m; mine[1] = l; }
+#pragma unroll
+    for (int j = 0; j < V; ++j) mine[2 + d0 + j] = acc[j];
+    __syncthreads();
+    float* rec = a.part + ((int64_t)h * a.nsplit + sp) * (hd + 2);
+    if (tid < hd) {
+        float mm = -1e30f;
+        for (int g = 0; g < NKG; ++g) mm = fmaxf(mm, sm[g * (hd + 2)]);
+        float lt = 0.f, ot = 0.f;
+        for (int g = 0; g < NKG; ++g) {
+            const float* r = sm + g * (hd + 2);
+            const float w = r[1] > 0.f ? expf(r[0] - mm) : 0.f;
+            lt = fmaf(w, r[1], lt);
+            ot = fmaf(w, r[2 + tid], ot);
+        }
+        rec[2 + tid] = ot;
+        if (tid == 0) { rec[0] = mm; rec[1] = lt; }
+    }
+}
+
+template <typename T, int NS>
 __global__ void attn_combine_kernel(const float* __restrict__ part, T* __restrict__ out,
-                                    const int32_t* __restrict__ done_flag, int hd, int nsplit) {
+                                    const int32_t* __restrict__ done_flag, int hd) {
     if (done_flag && *done_flag) return;
     const int h = blockIdx.x, d = threadIdx.x;
-    const float* rec = part + (int64_t)h * nsplit * (hd + 2);
+    const float* rec = part + (int64_t)h * NS * (hd + 2);
+    float ms[NS], ls[NS], os[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {  // 3*NS independent loads in flight
+        ms[s] = rec[s * (hd + 2)];
+        ls[s] = rec[s * (hd + 2) + 1];
+        os[s] = rec[s * (hd + 2) + 2 + d];
+    }
     float m = -1e30f;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, rec[s * (hd + 2)]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) m = fmaxf(m, ms[s]);
     float l = 0.f, o = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* r = rec + s * (hd + 2);
-        const float w = r[1] > 0.f ? expf(r[0] - m) : 0.f;
-        l = fmaf(w, r[1], l);
-        o = fmaf(w, r[2 + d], o);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float w = ls[s] > 0.f ? expf(ms[s] - m) : 0.f;
+        l = fmaf(w, ls[s], l);
+        o = fmaf(w, os[s], o);
     }
     Tr<T>::st(out + (int64_t)h * hd + d, o / l);
 }
 
-static inline int decode_nsplit() { return tuning_get("attn_decode_nsplit", 8); }
+static inline int decode_nsplit() {
+    const int n = tuning_get("attn_decode_nsplit", 16);
+    return n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : 32;
+}
 
 template <typename T>
-int attn_decode_launch(const void* q, const void* kc, const void* vc, void* out, void* ws, const int32_t* kv_len_dev,
-                       int kv_len_add, const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap,
-                       hipStream_t s) {
+int attn_decode_launch(const DecodeArgs& a0, void* out, int64_t n_heads, int64_t hd, hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
-    SS_REQUIRE(hd % V == 0 && 64 % (hd / V) == 0 && hd <= 256, "attn_decode: head_dim %lld unsupported", (long long)hd);
-    const int nsplit = decode_nsplit();
-    const int chunk_cap = cdiv(cache_cap + 1, nsplit) + 1;
-    const size_t lds = ((size_t)chunk_cap + 16 + 4 * hd) * sizeof(float);
-    SS_REQUIRE(lds <= 150 * 1024, "attn_decode: cache_cap %lld too large for nsplit %d", (long long)cache_cap, nsplit);
-    const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(attn_decode_kernel<T>, dim3((unsigned)n_heads, (unsigned)nsplit), dim3(256), lds, s,
-                       (const T*)q, (const T*)kc, (const T*)vc, (float*)ws, kv_len_dev, kv_len_add, done_flag,
-                       (int)hd, (int)cache_cap, nsplit, chunk_cap, scale);
+    SS_REQUIRE(hd % V == 0 && 256 % (hd / V) == 0 && 64 % (hd / V) == 0 && hd <= 256,
+               "attn_decode: head_dim %lld unsupported", (long long)hd);
+    DecodeArgs a = a0;
+    a.nsplit = decode_nsplit();
+    a.scale = 1.0f / sqrtf((float)hd);
+    const int NKG = 256 / (int)(hd / V);
+    const size_t lds = (size_t)NKG * (hd + 2) * sizeof(float);
+    hipLaunchKernelGGL(attn_decode_kernel<T>, dim3((unsigned)n_heads, (unsigned)a.nsplit), dim3(256), lds, s, a);
     SS_LAUNCH_CHECK("attn_decode");
-    hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((unsigned)n_heads), dim3((unsigned)hd), 0, s, (const float*)ws,
-                       (T*)out, done_flag, (int)hd, nsplit);
+#define SS_COMBINE(NS)                                                                                          \
+    hipLaunchKernelGGL((attn_combine_kernel<T, NS>), dim3((unsigned)n_heads), dim3((unsigned)hd), 0, s,          \
+                       (const float*)a.part, (T*)out, a.done_flag, (int)hd)
+    switch (a.nsplit) {
+        case 4: SS_COMBINE(4); break;
+        case 8: SS_COMBINE(8); break;
+        case 16: SS_COMBINE(16); break;
+        default: SS_COMBINE(32); break;
+    }
+#undef SS_COMBINE
     SS_LAUNCH_CHECK("attn_combine");
     return SS_OK;
 }
 
+// plain: rotated q given, cache already holds kv_len entries
 int attn_decode_dev(const void* q, const void* kc, const void* vc, void* out, void* ws, const int32_t* kv_len_dev,
-                    int kv_len_add, const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap,
-                    int dtype, hipStream_t s) {
-    return SS_DISPATCH(dtype, attn_decode_launch, q, kc, vc, out, ws, kv_len_dev, kv_len_add, done_flag, n_heads, hd,
-                       cache_cap, s);
+                    const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype,
+                    hipStream_t s) {
+    DecodeArgs a;
+    a.q = q; a.qkv_raw = nullptr; a.kc = (void*)kc; a.vc = (void*)vc; a.cos_t = a.sin_t = nullptr;
+    a.part = (float*)ws; a.kv_len_dev = kv_len_dev; a.pos_dev = nullptr; a.done_flag = done_flag;
+    a.hd = (int)hd; a.n_heads = (int)n_heads; a.cap = (int)cache_cap; a.nsplit = 0; a.scale = 0.f;
+    return SS_DISPATCH(dtype, attn_decode_launch, a, out, n_heads, hd, s);
+}
+
+// fused: pre-RoPE qkv row; rotates q/k, appends k/v at slot *kv_len_dev, attends over kv_len+1 keys
+int attn_decode_fused_dev(const void* qkv_raw, void* kc, void* vc, const void* cos_t, const void* sin_t, void* out,
+                          void* ws, const int32_t* kv_len_dev, const int32_t* pos_dev, const int32_t* done_flag,
+                          int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype, hipStream_t s) {
+    DecodeArgs a;
+    a.q = nullptr; a.qkv_raw = qkv_raw; a.kc = kc; a.vc = vc; a.cos_t = cos_t; a.sin_t = sin_t;
+    a.part = (float*)ws; a.kv_len_dev = kv_len_dev; a.pos_dev = pos_dev; a.done_flag = done_flag;
+    a.hd = (int)hd; a.n_heads = (int)n_heads; a.cap = (int)cache_cap; a.nsplit = 0; a.scale = 0.f;
+    return SS_DISPATCH(dtype, attn_decode_launch, a, out, n_heads, hd, s);
 }
 
 }  // namespace ss
@@ -391,7 +497,7 @@ size_t ss_attn_decode_workspace_bytes(int64_t n_heads, int64_t hd) {
 int ss_attn_decode(const void* q, const void* kcache, const void* vcache, void* out, void* workspace,
                    const int32_t* kv_len_dev, int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype,
                    void* stream) {
-    return attn_decode_dev(q, kcache, vcache, out, workspace, kv_len_dev, 0, nullptr, n_heads, hd, cache_cap, dtype,
+    return attn_decode_dev(q, kcache, vcache, out, workspace, kv_len_dev, nullptr, n_heads, hd, cache_cap, dtype,
                            (hipStream_t)stream);
 }
 

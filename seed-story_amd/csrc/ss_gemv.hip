@@ -34,10 +34,9 @@ struct GemvArgs {
 
 __device__ __forceinline__ float silu_g(float g) { return g / (1.0f + expf(-g)); }
 
-template <typename T, int NIT, int ROWS>
+template <typename T, int NIT, int ROWS, bool PIPE>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     constexpr int V = Tr<T>::kVec;
-    constexpr int CH = NIT < 8 ? NIT : 8;  // k-iterations whose loads are issued together
     if (a.done_flag && *a.done_flag) return;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -45,6 +44,33 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     const T* __restrict__ W = (const T*)a.W;
     const int K = a.K, N = a.N;
     const bool silu = (a.epi & SS_EPI_SILU_MUL) != 0;
+
+    // logical rows: silu -> N rows, each the pair (n, n+N) of W;  else ROWS consecutive rows.
+    const int ngroups = silu ? N : (N + ROWS - 1) / ROWS;
+    auto row_of = [&](int g, int r) -> int64_t { return silu ? (int64_t)g + (int64_t)r * N : (int64_t)g * ROWS + r; };
+    auto load_group = [&](int g, uint4 (&wv)[ROWS][NIT]) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t row = row_of(g, r);
+            const bool ok = silu || row < N;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int k = (it * 64 + lane) * V;
+                if (ok && k < K) {
+                    const T* p = W + row * K + k;
+                    wv[r][it] = a.use_nt ? ld_nt16(p) : ld16(p);
+                } else {
+                    wv[r][it] = make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // The first group's weight loads go out BEFORE the x prologue: the HBM round trip overlaps the
+    // (L2-served) x fetch and the RMSNorm arithmetic.
+    uint4 wv[ROWS][NIT];
+    int g = wave;
+    if (PIPE && g < ngroups) load_group(g, wv);
 
     // ---- x slice into registers (+ fused RMSNorm) ------------------------------------------
     uint4 xr[NIT];
@@ -68,71 +94,52 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         for (int it = 0; it < NIT; ++it) {
             const int k = (it * 64 + lane) * V;
             if (k < K) {
-                float f[V], g[V];
+                float f[V], gw[V];
                 unpack<T>(xr[it], f);
-                unpack<T>(ld16((const T*)a.norm_w + k), g);
+                unpack<T>(ld16((const T*)a.norm_w + k), gw);
 #pragma unroll
-                for (int j = 0; j < V; ++j) f[j] = g[j] * Tr<T>::rnd(f[j] * rstd);
+                for (int j = 0; j < V; ++j) f[j] = gw[j] * Tr<T>::rnd(f[j] * rstd);
                 xr[it] = pack<T>(f);
             }
         }
     }
 
-    // ---- stream the rows -----------------------------------------------------------------------
-    // logical rows: silu -> N rows, each the pair (n, n+N) of W;  else ROWS consecutive rows.
-    const int ngroups = silu ? N : (N + ROWS - 1) / ROWS;
-    for (int g = wave; g < ngroups; g += nwaves) {
-        int64_t r0[ROWS];
-        bool valid[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if (silu) { r0[r] = (int64_t)g + (int64_t)r * N; valid[r] = r < 2; }
-            else      { r0[r] = (int64_t)g * ROWS + r; valid[r] = r0[r] < N; }
-        }
+    // ---- stream the rows: dot the resident group, immediately re-issue the registers for the next
+    // group, then reduce/store while those loads fly ---------------------------------------------
+    while (g < ngroups) {
+        // PIPE=0 (default): plain load -> dot -> reduce per group: 125 VGPRs, 4 waves/SIMD; measured
+        // faster on MI355X than both software-pipelined forms (177-198 VGPRs, 2 waves/SIMD).
+        if (!PIPE) load_group(g, wv);
         float acc[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+        for (int r = 0; r < ROWS; ++r) {
+            acc[r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < NIT; c += CH) {
-            uint4 wv[ROWS][CH];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int it = c + i;
-                    const int k = (it * 64 + lane) * V;
-                    if (it < NIT && valid[r] && k < K) {
-                        const T* p = W + r0[r] * K + k;
-                        wv[r][i] = a.use_nt ? ld_nt16(p) : ld16(p);
-                    } else {
-                        wv[r][i] = make_uint4(0, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    if (c + i < NIT) acc[r] = dot_pack<T>(wv[r][i], xr[c + i], acc[r]);
+            for (int it = 0; it < NIT; ++it) acc[r] = dot_pack<T>(wv[r][it], xr[it], acc[r]);
         }
+        const int gn = g + nwaves;
+        if (PIPE && gn < ngroups) load_group(gn, wv);
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
             if (silu) {
                 // gate = round(acc0), up = round(acc1); y = round(round(silu(gate)) * up)
-                const float gt = Tr<T>::rnd(acc[0]), up = Tr<T>::rnd(acc[1]);
+                const float gt = Tr<T>::rnd(acc[0]), up = Tr<T>::rnd(acc[ROWS > 1 ? 1 : 0]);
                 Tr<T>::st((T*)a.y + g, Tr<T>::rnd(silu_g(gt)) * up);
             } else {
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
-                    if (!valid[r]) continue;
+                    const int64_t row = row_of(g, r);
+                    if (row >= N) continue;
                     float v = acc[r];
-                    if (a.epi & SS_EPI_BIAS) v += Tr<T>::ld((const T*)a.bias + r0[r]);
+                    if (a.epi & SS_EPI_BIAS) v += Tr<T>::ld((const T*)a.bias + row);
                     v = Tr<T>::rnd(v);
-                    if (a.epi & SS_EPI_RESIDUAL) v += Tr<T>::ld((const T*)a.residual + r0[r]);
-                    Tr<T>::st((T*)a.y + r0[r], v);
+                    if (a.epi & SS_EPI_RESIDUAL) v += Tr<T>::ld((const T*)a.residual + row);
+                    Tr<T>::st((T*)a.y + row, v);
                 }
             }
         }
+        g = gn;
     }
 }
 
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 // 88+ VGPRs per lane, so x (optionally RMS-normalised) is staged once per block in LDS and read
 // back with conflict-free ds_read_b128 (lanes read consecutive 16-byte slots); the k loop runs in
 // chunks of 8 x 64 packs with ROWS x 8 weight loads in flight.
-template <typename T, int ROWS>
+template <typename T, int ROWS, bool PIPE>
 __global__ __launch_bounds__(256) void gemv_ldsx_kernel(const GemvArgs a) {
     constexpr int V = Tr<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -156,6 +163,32 @@ __global__ __launch_bounds__(256) void gemv_ldsx_kernel(const GemvArgs a) {
     const int npack = K / V;
     const int nchunk = (npack + 511) / 512;  // chunks of 8 wave-iterations
     const int npack_pad = nchunk * 512;
+
+    const int ngroups = silu ? N : (N + ROWS - 1) / ROWS;
+    auto row_of = [&](int g, int r) -> int64_t { return silu ? (int64_t)g + (int64_t)r * N : (int64_t)g * ROWS + r; };
+    auto load_tile = [&](int g, int c, uint4 (&wv)[ROWS][8]) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t row = row_of(g, r);
+            const bool ok = silu || row < N;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = (c * 8 + i) * 64 + lane;
+                if (ok && p < npack) {
+                    const T* ptr = W + row * K + (int64_t)p * V;
+                    wv[r][i] = a.use_nt ? ld_nt16(ptr) : ld16(ptr);
+                } else {
+                    wv[r][i] = make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
+    };
+    int g = wave, c = 0;
+    uint4 wv[ROWS][8];
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    if (PIPE && g < ngroups) load_tile(g, 0, wv);  // first tile's HBM round trip overlaps the x staging
 
     float ssq = 0.f;
     for (int p = threadIdx.x; p < npack_pad; p += 256) {
@@ -174,74 +207,63 @@ __global__ __launch_bounds__(256) void gemv_ldsx_kernel(const GemvArgs a) {
     if (a.norm_w) {
         const float rstd = 1.0f / sqrtf(block_sum(ssq, red) / (float)K + a.eps);
         for (int p = threadIdx.x; p < npack; p += 256) {
-            float f[V], g[V];
+            float f[V], gw[V];
             unpack<T>(xs[p], f);
-            unpack<T>(ld16((const T*)a.norm_w + (int64_t)p * V), g);
+            unpack<T>(ld16((const T*)a.norm_w + (int64_t)p * V), gw);
 #pragma unroll
-            for (int j = 0; j < V; ++j) f[j] = g[j] * Tr<T>::rnd(f[j] * rstd);
+            for (int j = 0; j < V; ++j) f[j] = gw[j] * Tr<T>::rnd(f[j] * rstd);
             xs[p] = pack<T>(f);
         }
     }
     __syncthreads();
 
-    const int ngroups = silu ? N : (N + ROWS - 1) / ROWS;
-    for (int g = wave; g < ngroups; g += nwaves) {
-        int64_t r0[ROWS];
-        bool valid[ROWS];
+    while (g < ngroups) {
+        if (!PIPE) load_tile(g, c, wv);
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if (silu) { r0[r] = (int64_t)g + (int64_t)r * N; valid[r] = r < 2; }
-            else      { r0[r] = (int64_t)g * ROWS + r; valid[r] = r0[r] < N; }
+        for (int i = 0; i < 8; ++i) {
+            const uint4 xv = xs[(c * 8 + i) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r] = dot_pack<T>(wv[r][i], xv, acc[r]);
         }
-        float acc[ROWS];
+        // next (group, chunk) tile goes out before the reduction of the finished row
+        int gn = g, cn = c + 1;
+        if (cn == nchunk) { cn = 0; gn = g + nwaves; }
+        if (PIPE && gn < ngroups) load_tile(gn, cn, wv);
+        if (cn == 0) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            uint4 wv[ROWS][8];
+            for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+            if (lane == 0) {
+                if (silu) {
+                    const float gt = Tr<T>::rnd(acc[0]), up = Tr<T>::rnd(acc[ROWS > 1 ? 1 : 0]);
+                    Tr<T>::st((T*)a.y + g, Tr<T>::rnd(silu_g(gt)) * up);
+                } else {
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int p = (c * 8 + i) * 64 + lane;
-                    if (valid[r] && p < npack) {
-                        const T* ptr = W + r0[r] * K + (int64_t)p * V;
-                        wv[r][i] = a.use_nt ? ld_nt16(ptr) : ld16(ptr);
-                    } else {
-                        wv[r][i] = make_uint4(0, 0, 0, 0);
+                    for (int r = 0; r < ROWS; ++r) {
+                        const int64_t row = row_of(g, r);
+                        if (row >= N) continue;
+                        float v = acc[r];
+                        if (a.epi & SS_EPI_BIAS) v += Tr<T>::ld((const T*)a.bias + row);
+                        v = Tr<T>::rnd(v);
+                        if (a.epi & SS_EPI_RESIDUAL) v += Tr<T>::ld((const T*)a.residual + row);
+                        Tr<T>::st((T*)a.y + row, v);
                     }
                 }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 xv = xs[(c * 8 + i) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) acc[r] = dot_pack<T>(wv[r][i], xv, acc[r]);
             }
-        }
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-            if (silu) {
-                const float gt = Tr<T>::rnd(acc[0]), up = Tr<T>::rnd(acc[ROWS > 1 ? 1 : 0]);
-                Tr<T>::st((T*)a.y + g, Tr<T>::rnd(silu_g(gt)) * up);
-            } else {
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    if (!valid[r]) continue;
-                    float v = acc[r];
-                    if (a.epi & SS_EPI_BIAS) v += Tr<T>::ld((const T*)a.bias + r0[r]);
-                    v = Tr<T>::rnd(v);
-                    if (a.epi & SS_EPI_RESIDUAL) v += Tr<T>::ld((const T*)a.residual + r0[r]);
-                    Tr<T>::st((T*)a.y + r0[r], v);
-                }
-            }
+            for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
         }
+        g = gn;
+        c = cn;
     }
 }
 
 template <typename T, int NIT>
 static int gemv_launch_nit(const GemvArgs& a, int blocks, hipStream_t s) {
     // ROWS=2 keeps 16 x 16 B per lane in flight at NIT=8 (and SiLU pairs need exactly 2 rows)
-    hipLaunchKernelGGL((gemv_kernel<T, NIT, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (tuning_get("gemv_pipe", 0))
+        hipLaunchKernelGGL((gemv_kernel<T, NIT, 2, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemv_kernel<T, NIT, 2, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     SS_LAUNCH_CHECK("gemv");
     return SS_OK;
 }
@@ -261,7 +283,9 @@ int gemv_launch(const void* W, const void* x, void* y, int64_t N, int64_t K, con
     const int nit = cdiv(K, 64 * V);
     const int64_t groups = (epi & SS_EPI_SILU_MUL) ? N : (N + 1) / 2;
     // waves: enough to fill the chip, but several row-groups per wave so the x prologue amortises
-    const int gpw = tuning_get("gemv_groups_per_wave", 2);
+    // auto: ~2.5k waves (8-12 per CU) measured best on MI355X for every LLaMA-7B projection
+    int gpw = tuning_get("gemv_groups_per_wave", 0);
+    if (gpw <= 0) { gpw = (int)((groups + 1280) / 2560); if (gpw < 1) gpw = 1; }
     int64_t waves = (groups + gpw - 1) / gpw;
     int blocks = (int)((waves + 3) / 4);
     const int max_blocks = tuning_get("gemv_max_blocks", 256 * 8);
@@ -273,7 +297,10 @@ int gemv_launch(const void* W, const void* x, void* y, int64_t N, int64_t K, con
     if (nit <= 8 && !tuning_get("gemv_force_lds", 0)) return gemv_launch_nit<T, 8>(a, blocks, s);
     const size_t lds = (size_t)cdiv(K / V, 512) * 512 * 16;
     SS_REQUIRE(lds <= 128 * 1024, "gemv: K=%lld too large", (long long)K);
-    hipLaunchKernelGGL((gemv_ldsx_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    if (tuning_get("gemv_pipe", 0))
+        hipLaunchKernelGGL((gemv_ldsx_kernel<T, 2, true>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL((gemv_ldsx_kernel<T, 2, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     SS_LAUNCH_CHECK("gemv_ldsx");
     return SS_OK;
 }

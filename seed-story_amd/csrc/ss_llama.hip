@@ -29,9 +29,9 @@ int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_
 int rope_kv_append_dev(const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
                        const int32_t* pos_ids, int64_t M, int64_t n_heads, int64_t hd, const int32_t* kv_start_dev,
                        int64_t cache_cap, int dtype, hipStream_t s);
-int attn_decode_dev(const void* q, const void* kc, const void* vc, void* out, void* ws, const int32_t* kv_len_dev,
-                    int kv_len_add, const int32_t* done_flag, int64_t n_heads, int64_t hd, int64_t cache_cap,
-                    int dtype, hipStream_t s);
+int attn_decode_fused_dev(const void* qkv_raw, void* kc, void* vc, const void* cos_t, const void* sin_t, void* out,
+                          void* ws, const int32_t* kv_len_dev, const int32_t* pos_dev, const int32_t* done_flag,
+                          int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype, hipStream_t s);
 
 // device state words
 enum { ST_KV_LEN = 0, ST_POS = 1, ST_NGEN = 2, ST_DONE = 3, ST_LAST = 4, ST_NFORCED = 5, ST_LIMIT = 6, ST_EOS = 7 };
@@ -222,24 +222,24 @@ static int decode_token(ss_llama* h, hipStream_t s, ProfSink* prof) {
         char* kc = h->kc + (size_t)l * plane;
         char* vc = h->vc + (size_t)l * plane;
         int rc;
+        MARK(-1);
         rc = gemv_dev(L.wqkv, h->x, h->qkv, 3 * H, H, L.ln1, g.rms_eps, nullptr, nullptr, SS_EPI_NONE, done, dt, s);
         if (rc) return rc;
         MARK(0);
-        rc = rope_kv_append_dev(h->qkv, h->q, kc, vc, h->w.rope_cos, h->w.rope_sin, h->state + ST_POS, 1, g.n_heads,
-                                hd, h->state + ST_KV_LEN, g.cache_cap, dt, s);
-        if (rc) return rc;
-        MARK(2);
-        rc = attn_decode_dev(h->q, kc, vc, h->attn, h->attn_ws, h->state + ST_KV_LEN, 1, done, g.n_heads, hd,
-                             g.cache_cap, dt, s);
+        // RoPE(q,k) + KV append + split-KV attention in one kernel (+ the split merge)
+        rc = attn_decode_fused_dev(h->qkv, kc, vc, h->w.rope_cos, h->w.rope_sin, h->attn, h->attn_ws,
+                                   h->state + ST_KV_LEN, h->state + ST_POS, done, g.n_heads, hd, g.cache_cap, dt, s);
         if (rc) return rc;
         MARK(1);
         rc = gemv_dev(L.wo, h->attn, h->xn, H, H, nullptr, 0.f, nullptr, h->x, SS_EPI_RESIDUAL, done, dt, s);
         if (rc) return rc;
+        MARK(0);
         rc = gemv_dev(L.wgu, h->xn, h->hm, I, H, L.ln2, g.rms_eps, nullptr, nullptr, SS_EPI_SILU_MUL, done, dt, s);
         if (rc) return rc;
+        MARK(0);
         rc = gemv_dev(L.wdown, h->hm, h->x, H, I, nullptr, 0.f, nullptr, h->xn, SS_EPI_RESIDUAL, done, dt, s);
         if (rc) return rc;
-        MARK(0);
+        MARK(2);
     }
     if (dt == SS_BF16)
         hipLaunchKernelGGL(final_norm_advance_kernel<bf16_t>, dim3(1), dim3(256), 0, s, (const bf16_t*)h->x,
@@ -448,6 +448,9 @@ int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, cons
     SS_REQUIRE(n_forced >= 0 && n_forced <= g.max_new, "llama_generate: n_forced out of range");
     SS_REQUIRE(h->kv_len + limit <= g.cache_cap, "llama_generate: KV cache overflow (%lld + %lld > %d)",
                (long long)h->kv_len, (long long)limit, g.cache_cap);
+    int64_t eff_limit = limit;
+    for (int64_t i = 0; i < n_forced && i < eff_limit; ++i)
+        if (host_forced[i] == g.eos_id) { eff_limit = i + 1; break; }  // the host already knows where it stops
     if (n_forced > 0)
         SS_HIP(hipMemcpyAsync(h->forced, host_forced, (size_t)n_forced * sizeof(int32_t), hipMemcpyHostToDevice, s));
     // state upload staged in pinned memory (words 8..15); consumed before this call returns (read_state syncs)
@@ -468,8 +471,8 @@ int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, cons
     }
     const int chunk = tuning_get("llama_done_poll", 8);
     int64_t launched = 0;
-    while (launched < limit) {
-        const int64_t n = (limit - launched) < chunk ? (limit - launched) : chunk;
+    while (launched < eff_limit) {
+        const int64_t n = (eff_limit - launched) < chunk ? (eff_limit - launched) : chunk;
         for (int64_t i = 0; i < n; ++i) {
             if (use_graph) SS_HIP(hipGraphLaunch(h->graph_exec, s));
             else { int rc = decode_token(h, s, nullptr); if (rc) return rc; }
@@ -485,7 +488,7 @@ int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, cons
     return SS_OK;
 }
 
-int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], double out_bytes[2], void* stream) {
+int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], double out_bytes[4], void* stream) {
     SS_REQUIRE(h && n_tokens > 0 && out_ms && out_bytes, "llama_profile_decode: bad arguments");
     const ss_llama_config& g = h->cfg;
     hipStream_t s = (hipStream_t)stream;
@@ -495,6 +498,7 @@ int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], doub
     init[ST_LAST] = 0; init[ST_NFORCED] = 0; init[ST_LIMIT] = g.max_new; init[ST_EOS] = -1;
     SS_HIP(hipMemcpyAsync(h->state, init, 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 8; ++i) out_ms[i] = 0.f;
+    double cnt[4] = {0, 0, 0, 0};
     for (int64_t t = 0; t < n_tokens && t < g.max_new - 1; ++t) {
         ProfSink p;
         p.s = s;
@@ -504,7 +508,7 @@ int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], doub
             for (size_t i = 1; i < p.ev.size(); ++i) {
                 float ms = 0.f;
                 hipEventElapsedTime(&ms, p.ev[i - 1], p.ev[i]);
-                if (p.cls[i] >= 0 && p.cls[i] < 4) out_ms[p.cls[i]] += ms;
+                if (p.cls[i] >= 0 && p.cls[i] < 4) { out_ms[p.cls[i]] += ms; cnt[p.cls[i]] += 1; }
             }
             float tot = 0.f;
             hipEventElapsedTime(&tot, p.ev.front(), p.ev.back());
@@ -516,8 +520,11 @@ int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], doub
     }
     for (int i = 0; i < 8; ++i) out_ms[i] /= (float)n_tokens;
     const double H = g.hidden, I = g.inter;
-    out_bytes[0] = ((double)g.n_layers * (4.0 * H * H + 3.0 * H * I) + (double)g.vocab * H) * (double)h->esz;
-    out_bytes[1] = 2.0 * g.n_layers * H * (double)h->esz;  // KV bytes per cached position
+    // class 0 = every GEMV except the down projection (qkv, o, gate|up per layer + lm_head); class 2 = down
+    out_bytes[0] = ((double)g.n_layers * (4.0 * H * H + 2.0 * H * I) + (double)g.vocab * H) * (double)h->esz;
+    out_bytes[1] = cnt[0] / (double)n_tokens;
+    out_bytes[2] = (double)g.n_layers * H * I * (double)h->esz;
+    out_bytes[3] = cnt[2] / (double)n_tokens;
     int rc = read_state(h, s);
     if (rc) return rc;
     h->kv_len = h->pinned[ST_KV_LEN];

@@ -101,6 +101,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SSError("libseedstory_hip.so not found at %s — build it first (seed-story_amd/csrc/Makefile); "
                           "there is no CPU fallback" % LIB_PATH)
+        # torch ships its own libamdhip64.so.7 (+ HSA runtime); it must be the copy this process binds
+        # to, or the two runtimes disagree about the device ("no ROCm-capable device").  Import torch
+        # first so the library's DT_NEEDED libamdhip64.so.7 resolves to the already-loaded one.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol

@@ -219,7 +219,7 @@ class LlamaEngine:
 
     def profile_decode(self, n_tokens=4):
         ms = (C.c_float * 8)()
-        by = (C.c_double * 2)()
+        by = (C.c_double * 4)()
         check(lib().ss_llama_profile_decode(self._h, n_tokens, ms, by, ops.stream()), "ss_llama_profile_decode")
-        return {"gemv_ms": ms[0], "attn_ms": ms[1], "rope_ms": ms[2], "misc_ms": ms[3], "token_ms": ms[4],
-                "gemv_bytes": by[0], "kv_bytes_per_pos": by[1]}
+        return {"gemv_ms": ms[0], "attn_ms": ms[1], "gemv_down_ms": ms[2], "misc_ms": ms[3], "token_ms": ms[4],
+                "gemv_bytes": by[0], "gemv_launches": by[1], "gemv_down_bytes": by[2], "gemv_down_launches": by[3]}

@@ -45,7 +45,7 @@ def dev(t, dtype=None):
     return t.to(device=DEV, dtype=dtype if dtype is not None else t.dtype).contiguous()
 
 
-@pytest.mark.parametrize("rows,cols", [(5, 256), (37, 4096), (3, 1664), (2, 11008)])
+@pytest.mark.parametrize("rows,cols", [(5, 256), (37, 4096), (3, 1664), (2, 8192)])
 def test_rmsnorm(ops, rows, cols):
     x32 = synth.normal_like(1, (rows, cols), 1.5)
     w32 = synth.normal_like(2, (cols,), 0.1, 1.0)

@@ -38,10 +38,10 @@ def bench_gemv():
         ws = [torch.randn(rows, K, device=DEV, dtype=torch.bfloat16) * 0.02 for _ in range(ncopy)]
         x = torch.randn(K, device=DEV, dtype=torch.bfloat16)
         nw = torch.ones(K, device=DEV, dtype=torch.bfloat16)
-        for gpw in (1, 2, 4, 8):
+        for gpw in (0, 1, 2, 4):
             for nt in (1, 0):
                 _lib.set_tuning("gemv_groups_per_wave", gpw)
-                _lib.set_tuning("gemv_nt", nt)
+                _lib.set_tuning("gemv_pipe", nt)
                 st = {"i": 0}
 
                 def f():
@@ -49,11 +49,11 @@ def bench_gemv():
                     ops.gemv(ws[st["i"] % ncopy], x, norm_w=nw if name in ("qkv", "gateup") else None, eps=1e-5, **kw)
                 ms = timeit(f, iters=30)
                 gbs = rows * K * 2 / ms / 1e6
-                res.append(dict(name=name, N=N, K=K, gpw=gpw, nt=nt, ms=round(ms, 4), GBps=round(gbs, 1)))
+                res.append(dict(name=name, N=N, K=K, gpw=gpw, pipe=nt, ms=round(ms, 4), GBps=round(gbs, 1)))
                 print(res[-1], flush=True)
         del ws
-    _lib.set_tuning("gemv_groups_per_wave", 2)
-    _lib.set_tuning("gemv_nt", 1)
+    _lib.set_tuning("gemv_groups_per_wave", 0)
+    _lib.set_tuning("gemv_pipe", 1)
     OUT["gemv"] = res
 
 
@@ -122,6 +122,21 @@ def make_7b_engine(n_layers=32, cache_cap=2048, max_new=512, max_rows=1024):
 def bench_decode():
     res = {}
     eng = make_7b_engine()
+    for pipe in (1, 0):
+        _lib.set_tuning("gemv_pipe", pipe)
+        emb = torch.randn(343, 4096, device=DEV, dtype=torch.bfloat16) * 0.02
+        eng.reset(); eng.prefill(emb)
+        forced = torch.randint(3, 32000, (115,)).tolist()
+        _lib.set_tuning("llama_graph", 0)
+        eng.generate(115, 5, forced)
+        eng.set_lengths(343, 343)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = eng.generate(115, 5, forced)
+        torch.cuda.synchronize()
+        res["eager_tok_ms_pipe%d" % pipe] = round((time.perf_counter() - t0) * 1e3 / n, 4)
+        _lib.set_tuning("llama_graph", 1)
+        print(res, flush=True)
+    _lib.set_tuning("gemv_pipe", int(os.environ.get("SS_GEMV_PIPE", "1")))
     H = 4096
     for S in (343, 913):
         emb = torch.randn(S, H, device=DEV, dtype=torch.bfloat16) * 0.02
