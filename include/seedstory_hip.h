@@ -282,6 +282,50 @@ size_t ss_vit_workspace_bytes(const ss_vit_weights* w, int64_t batch, int dtype)
 int ss_vit_forward(const ss_vit_weights* w, const void* img, void* out, int64_t batch, void* workspace,
                    size_t workspace_bytes, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SDXL de-tokenizer half (the reference reaches these ops through diffusers:
+ * src/models_ipa/adapter_modules.py:455-466, gen_george.py:60-64).
+ * Activations are NHWC: [batch, H*W, C] row-major.
+ * ------------------------------------------------------------------------------------- */
+
+/* 3x3 convolution, padding 1, stride 1|2, as an implicit GEMM on the matrix cores (diffusers
+ * ResnetBlock2D.conv1/conv2, Downsample2D.conv, Upsample2D.conv, conv_in/conv_out):
+ * x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; w [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci (re-laid once at
+ * load); upsample2x fuses F.interpolate(scale 2, nearest) of the input into the gather;
+ * bias [Cout] | NULL; rowvec [B, Cout] | NULL is added after the bias (ResBlock time embedding,
+ * `h + temb[:, :, None, None]`); residual [B,Ho,Wo,Cout] | NULL is added last. Cin % 8 == 0. */
+int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, int64_t W, int64_t Cin,
+               int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
+               const void* residual, int dtype, void* stream);
+
+/* nn.GroupNorm over NHWC (+ optional fused SiLU): fp32 statistics per (batch, group);
+ * stats_ws = batch*groups*2 floats of scratch. */
+int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch,
+                 int64_t hw, int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream);
+
+/* diffusers GEGLU: in [rows, 2d] = [value | gate] -> out[r,i] = value * gelu_erf(gate). */
+int ss_geglu(const void* in, void* out, int64_t rows, int64_t d, int dtype, void* stream);
+/* y = silu(x) (op 0) | gelu_erf(x) (op 1), element-wise (time-embedding activations). */
+int ss_unary(const void* x, void* y, int64_t n, int op, int dtype, void* stream);
+/* in-place row softmax of scores[rows, cols] * scale (VAE mid-block attention, head_dim 512). */
+int ss_softmax_rows(void* scores, int64_t rows, int64_t cols, float scale, int dtype, void* stream);
+/* out[c, r] = in[r, c] */
+int ss_transpose(const void* in, void* out, int64_t rows, int64_t cols, int dtype, void* stream);
+/* out[r, :] = [a[r, :c1] | b[r, :c2]]  (torch.cat([h, skip], dim=1) of the UNet up path, NHWC). */
+int ss_concat_channels(const void* a, const void* b, void* out, int64_t rows, int64_t c1, int64_t c2, int dtype,
+                       void* stream);
+/* NCHW [B,C,HW] <-> NHWC [B,HW,cpad] (zero padded channels) for the 4-channel latents. */
+int ss_layout_nchw_nhwc(const void* in, void* out, int64_t batch, int64_t channels, int64_t hw, int64_t cpad,
+                        int to_nhwc, int dtype, void* stream);
+/* EulerDiscreteScheduler.scale_model_input + CFG duplication: xin[0] = xin[1] = x / sqrt(sigma^2+1). */
+int ss_euler_scale_dup(const void* x, void* xin, int64_t n, float sigma, int dtype, void* stream);
+/* e = eps[0] + guidance * (eps[1] - eps[0]);  x += e * (sigma_next - sigma)   (adapter_modules.py:437;
+ * EulerDiscreteScheduler.step, epsilon prediction). eps = [uncond; cond], n elements each. */
+int ss_euler_cfg_step(void* x, const void* eps, int64_t n, float guidance, float sigma, float sigma_next,
+                      int dtype, void* stream);
+/* VAE output NHWC [pixels, cpad] -> uint8 HWC: round(clamp(x/2 + 0.5, 0, 1) * 255). */
+int ss_image_to_u8(const void* in, void* out_u8, int64_t pixels, int64_t cpad, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

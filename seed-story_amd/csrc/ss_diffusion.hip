@@ -1,0 +1,389 @@
+// HBM-bound kernels of the SDXL de-tokenizer half (UNet ResBlocks / Transformer2D, VAE decoder,
+// Euler + classifier-free guidance) — the reference reaches these through diffusers
+// (src/models_ipa/adapter_modules.py:455-466).
+// Activations are NHWC ([B, H*W, C] row-major) so every convolution is an implicit GEMM over
+// channels (ss_gemm.hip) and the transformer blocks need no permutes.
+#include "ss_common.h"
+
+namespace ss {
+
+__device__ __forceinline__ float silu_d(float g) { return g / (1.0f + expf(-g)); }
+__device__ __forceinline__ float gelu_d(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// =====================================================================================
+// GroupNorm over NHWC: statistics per (batch, group) of H*W x (C/G) elements.
+//   pass 1: partial sum / sum-of-squares per block -> fp32 atomics into stats[b][g][2]
+//   pass 2: y = (x - mean) * rstd * gamma[c] + beta[c]  (+ SiLU), rounded once to T
+// (torch GroupNorm computes in fp32 and rounds the result; SiLU then rounds again.)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
+                                                              int HW, int C, int G, int rows_per_block) {
+    // One block = a range of pixels x ALL channels (full 16-byte coalesced rows, any channels-per-group,
+    // e.g. 10 for C=320).  Per-pack partial sums go to LDS atomics (<= 4-way same-address contention),
+    // then 2*G global fp32 atomics per block.
+    constexpr int V = Tr<T>::kVec;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sh = reinterpret_cast<float*>(smem_raw);  // [G][2]
+    const int b = blockIdx.y;
+    const int cg = C / G, ppr = C / V;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const T* xb = x + ((int64_t)b * HW) * C;
+    const int total = (r1 - r0) * ppr;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int r = r0 + i / ppr, p = i % ppr;
+        float f[V];
+        unpack<T>(ld16(xb + (int64_t)r * C + p * V), f);
+        int g = (p * V) / cg;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int gj = (p * V + j) / cg;
+            if (gj != g) {
+                atomicAdd(sh + 2 * g, s1);
+                atomicAdd(sh + 2 * g + 1, s2);
+                g = gj; s1 = 0.f; s2 = 0.f;
+            }
+            s1 += f[j];
+            s2 = fmaf(f[j], f[j], s2);
+        }
+        atomicAdd(sh + 2 * g, s1);
+        atomicAdd(sh + 2 * g + 1, s2);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(stats + (int64_t)b * G * 2 + i, sh[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                              T* __restrict__ y, int64_t B, int HW, int C, int G,
+                                                              float eps, int silu) {
+    constexpr int V = Tr<T>::kVec;
+    const int cg = C / G;
+    const int ppr = C / V;
+    const int64_t total = B * HW * (int64_t)ppr;
+    const float inv_n = 1.0f / ((float)HW * (float)cg);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % ppr);
+        const int64_t row = i / ppr;
+        const int b = (int)(row / HW);
+        const int c0 = p * V;
+        float f[V], ga[V], be[V];
+        unpack<T>(ld16(x + row * C + c0), f);
+        unpack<T>(ld16(gamma + c0), ga);
+        unpack<T>(ld16(beta + c0), be);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int g = (c0 + j) / cg;
+            const float s1 = stats[((int64_t)b * G + g) * 2], s2 = stats[((int64_t)b * G + g) * 2 + 1];
+            const float mean = s1 * inv_n;
+            const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + eps);
+            float v = (f[j] - mean) * rstd * ga[j] + be[j];
+            if (silu) v = silu_d(Tr<T>::rnd(v));
+            f[j] = v;
+        }
+        st16(y + row * C + c0, pack<T>(f));
+    }
+}
+
+template <typename T>
+int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, float* stats, int64_t B, int64_t HW,
+                     int64_t C, int64_t G, float eps, int silu, hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    SS_REQUIRE(C % G == 0 && C % V == 0, "groupnorm: C=%lld G=%lld unsupported", (long long)C, (long long)G);
+    if (B * HW == 0) return SS_OK;
+    SS_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), s));
+    // ~256 KiB of activations per block, at least enough blocks to fill the chip
+    int rows_per_block = (int)((256 * 1024) / (C * sizeof(T)));
+    if (rows_per_block < 16) rows_per_block = 16;
+    while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 512) rows_per_block /= 2;
+    if (rows_per_block > HW) rows_per_block = (int)HW;
+    dim3 grid((unsigned)cdiv(HW, rows_per_block), (unsigned)B);
+    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), (size_t)G * 2 * sizeof(float), s, (const T*)x, stats,
+                       (int)HW, (int)C, (int)G, rows_per_block);
+    SS_LAUNCH_CHECK("groupnorm_stats");
+    int64_t blocks = (B * HW * (C / V) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(groupnorm_apply_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, stats,
+                       (const T*)gamma, (const T*)beta, (T*)y, B, (int)HW, (int)C, (int)G, eps, silu);
+    SS_LAUNCH_CHECK("groupnorm_apply");
+    return SS_OK;
+}
+
+// =====================================================================================
+// small element-wise / layout kernels
+// =====================================================================================
+// GEGLU: out[r, i] = val[r, i] * gelu(gate[r, i]); in [rows, 2D] = [val | gate]  (diffusers GEGLU)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t rows, int D) {
+    constexpr int V = Tr<T>::kVec;
+    const int ppr = D / V;
+    const int64_t total = rows * ppr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ppr;
+        const int p = (int)(i % ppr);
+        float a[V], g[V];
+        unpack<T>(ld16(in + r * 2 * D + (int64_t)p * V), a);
+        unpack<T>(ld16(in + r * 2 * D + D + (int64_t)p * V), g);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = a[j] * Tr<T>::rnd(gelu_d(g[j]));
+        st16(out + r * D + (int64_t)p * V, pack<T>(a));
+    }
+}
+
+// in-place row softmax of s[rows, cols] * scale (fp32 math, rounded to T)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ s, int cols, float scale) {
+    constexpr int V = Tr<T>::kVec;
+    __shared__ float red[16];
+    T* row = s + (int64_t)blockIdx.x * cols;
+    const int npack = cols / V;
+    float mx = -1e30f;
+    for (int p = threadIdx.x; p < npack; p += 256) {
+        float f[V];
+        unpack<T>(ld16(row + (int64_t)p * V), f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) mx = fmaxf(mx, f[j] * scale);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int p = threadIdx.x; p < npack; p += 256) {
+        float f[V];
+        unpack<T>(ld16(row + (int64_t)p * V), f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) sum += expf(f[j] * scale - mx);
+    }
+    sum = block_sum(sum, red);
+    const float inv = 1.0f / sum;
+    for (int p = threadIdx.x; p < npack; p += 256) {
+        float f[V];
+        unpack<T>(ld16(row + (int64_t)p * V), f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = expf(f[j] * scale - mx) * inv;
+        st16(row + (int64_t)p * V, pack<T>(f));
+    }
+}
+
+// out[c, r] = in[r, c]  (32x32 LDS tile transpose)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int Cc) {
+    __shared__ T tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < Cc) tile[j][tx] = in[(int64_t)(r0 + j) * Cc + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < Cc && r0 + tx < R) out[(int64_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
+// out[r, :C1] = a[r, :], out[r, C1:] = b[r, :]   (channel concat of two NHWC tensors: torch.cat(dim=1) in NCHW)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_channels_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              T* __restrict__ out, int64_t rows, int C1, int C2) {
+    constexpr int V = Tr<T>::kVec;
+    const int ppr = (C1 + C2) / V, p1 = C1 / V;
+    const int64_t total = rows * ppr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ppr;
+        const int p = (int)(i % ppr);
+        const uint4 v = p < p1 ? ld16(a + r * C1 + (int64_t)p * V) : ld16(b + r * C2 + (int64_t)(p - p1) * V);
+        st16(out + r * (C1 + C2) + (int64_t)p * V, v);
+    }
+}
+
+// NCHW [B, C, HW] <-> NHWC [B, HW, Cpad] for the tiny latent tensors (C = 4 -> Cpad = 8, zero padded)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t B, int C, int HW, int Cpad) {
+    const int64_t total = B * HW * Cpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const int64_t r = i / Cpad;
+        const int64_t b = r / HW, px = r % HW;
+        T v;
+        if (c < C) v = in[(b * C + c) * HW + px]; else Tr<T>::st(&v, 0.f);
+        out[i] = v;
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t B, int C, int HW, int Cpad) {
+    const int64_t total = B * C * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i % HW;
+        const int64_t bc = i / HW;
+        const int c = (int)(bc % C);
+        const int64_t b = bc / C;
+        out[i] = in[(b * HW + px) * Cpad + c];
+    }
+}
+
+// EulerDiscreteScheduler.scale_model_input + CFG duplication: xin[0] = xin[1] = x / sqrt(sigma^2 + 1)
+// classifier-free guidance + Euler step:  e = eu + g (ec - eu);  x += e * (sigma_next - sigma)
+// (fp32 latents like diffusers keeps them when the pipeline dtype is fp32; T otherwise)
+template <typename T>
+__global__ void euler_scale_dup_kernel(const T* __restrict__ x, T* __restrict__ xin, int64_t n, float inv) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = Tr<T>::ld(x + i) * inv;
+        Tr<T>::st(xin + i, v);
+        Tr<T>::st(xin + n + i, v);
+    }
+}
+template <typename T>
+__global__ void euler_cfg_step_kernel(T* __restrict__ x, const T* __restrict__ eps, int64_t n, float guidance, float dsigma) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float eu = Tr<T>::ld(eps + i), ec = Tr<T>::ld(eps + n + i);
+        const float e = Tr<T>::rnd(eu + Tr<T>::rnd(guidance * Tr<T>::rnd(ec - eu)));
+        Tr<T>::st(x + i, Tr<T>::ld(x + i) + Tr<T>::rnd(e * dsigma));
+    }
+}
+
+// VAE output NHWC [B, HW, Cpad] (first 3 channels) -> uint8 HWC: round(clamp(x/2 + 0.5, 0, 1) * 255)
+template <typename T>
+__global__ void image_to_u8_kernel(const T* __restrict__ in, uint8_t* __restrict__ out, int64_t pixels, int Cpad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pixels * 3; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const int64_t px = i / 3;
+        float v = Tr<T>::rnd(Tr<T>::ld(in + px * Cpad + c) * 0.5f + 0.5f);
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
+// y = silu(x) | gelu(x), rounded to T  (time-embedding activations: F.silu(emb))
+template <typename T>
+__global__ void unary_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int op) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = Tr<T>::ld(x + i);
+        Tr<T>::st(y + i, op == 0 ? silu_d(v) : gelu_d(v));
+    }
+}
+
+static inline unsigned egrid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+template <typename T>
+int geglu_launch(const void* in, void* out, int64_t rows, int64_t D, hipStream_t s) {
+    SS_REQUIRE(D % Tr<T>::kVec == 0, "geglu: D %% %d != 0", Tr<T>::kVec);
+    if (rows == 0) return SS_OK;
+    hipLaunchKernelGGL(geglu_kernel<T>, dim3(egrid(rows * D / Tr<T>::kVec)), dim3(256), 0, s, (const T*)in, (T*)out, rows, (int)D);
+    SS_LAUNCH_CHECK("geglu");
+    return SS_OK;
+}
+template <typename T>
+int unary_launch(const void* x, void* y, int64_t n, int op, hipStream_t s) {
+    if (n == 0) return SS_OK;
+    hipLaunchKernelGGL(unary_kernel<T>, dim3(egrid(n)), dim3(256), 0, s, (const T*)x, (T*)y, n, op);
+    SS_LAUNCH_CHECK("unary");
+    return SS_OK;
+}
+template <typename T>
+int softmax_rows_launch(void* sc, int64_t rows, int64_t cols, float scale, hipStream_t s) {
+    SS_REQUIRE(cols % Tr<T>::kVec == 0, "softmax_rows: cols %% %d != 0", Tr<T>::kVec);
+    if (rows == 0) return SS_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3((unsigned)rows), dim3(256), 0, s, (T*)sc, (int)cols, scale);
+    SS_LAUNCH_CHECK("softmax_rows");
+    return SS_OK;
+}
+template <typename T>
+int transpose_launch(const void* in, void* out, int64_t R, int64_t Cc, hipStream_t s) {
+    if (R * Cc == 0) return SS_OK;
+    hipLaunchKernelGGL(transpose_kernel<T>, dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(256), 0, s,
+                       (const T*)in, (T*)out, (int)R, (int)Cc);
+    SS_LAUNCH_CHECK("transpose");
+    return SS_OK;
+}
+template <typename T>
+int concat_channels_launch(const void* a, const void* b, void* out, int64_t rows, int64_t C1, int64_t C2, hipStream_t s) {
+    SS_REQUIRE(C1 % Tr<T>::kVec == 0 && C2 % Tr<T>::kVec == 0, "concat_channels: channels %% %d != 0", Tr<T>::kVec);
+    if (rows == 0) return SS_OK;
+    hipLaunchKernelGGL(concat_channels_kernel<T>, dim3(egrid(rows * (C1 + C2) / Tr<T>::kVec)), dim3(256), 0, s,
+                       (const T*)a, (const T*)b, (T*)out, rows, (int)C1, (int)C2);
+    SS_LAUNCH_CHECK("concat_channels");
+    return SS_OK;
+}
+template <typename T>
+int layout_launch(const void* in, void* out, int64_t B, int64_t C, int64_t HW, int64_t Cpad, int to_nhwc, hipStream_t s) {
+    if (B * HW == 0) return SS_OK;
+    if (to_nhwc)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(egrid(B * HW * Cpad)), dim3(256), 0, s, (const T*)in, (T*)out, B,
+                           (int)C, (int)HW, (int)Cpad);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(egrid(B * C * HW)), dim3(256), 0, s, (const T*)in, (T*)out, B,
+                           (int)C, (int)HW, (int)Cpad);
+    SS_LAUNCH_CHECK("layout");
+    return SS_OK;
+}
+template <typename T>
+int euler_scale_dup_launch(const void* x, void* xin, int64_t n, float sigma, hipStream_t s) {
+    hipLaunchKernelGGL(euler_scale_dup_kernel<T>, dim3(egrid(n)), dim3(256), 0, s, (const T*)x, (T*)xin, n,
+                       1.0f / sqrtf(sigma * sigma + 1.0f));
+    SS_LAUNCH_CHECK("euler_scale_dup");
+    return SS_OK;
+}
+template <typename T>
+int euler_cfg_step_launch(void* x, const void* eps, int64_t n, float guidance, float sigma, float sigma_next, hipStream_t s) {
+    hipLaunchKernelGGL(euler_cfg_step_kernel<T>, dim3(egrid(n)), dim3(256), 0, s, (T*)x, (const T*)eps, n, guidance,
+                       sigma_next - sigma);
+    SS_LAUNCH_CHECK("euler_cfg_step");
+    return SS_OK;
+}
+template <typename T>
+int image_to_u8_launch(const void* in, void* out, int64_t pixels, int64_t Cpad, hipStream_t s) {
+    hipLaunchKernelGGL(image_to_u8_kernel<T>, dim3(egrid(pixels * 3)), dim3(256), 0, s, (const T*)in, (uint8_t*)out, pixels,
+                       (int)Cpad);
+    SS_LAUNCH_CHECK("image_to_u8");
+    return SS_OK;
+}
+
+}  // namespace ss
+
+using namespace ss;
+
+extern "C" {
+
+int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch, int64_t hw,
+                 int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, groupnorm_launch, x, gamma, beta, y, (float*)stats_ws, batch, hw, channels, groups, eps,
+                       fuse_silu, (hipStream_t)stream);
+}
+int ss_geglu(const void* in, void* out, int64_t rows, int64_t d, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, geglu_launch, in, out, rows, d, (hipStream_t)stream);
+}
+int ss_unary(const void* x, void* y, int64_t n, int op, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, unary_launch, x, y, n, op, (hipStream_t)stream);
+}
+int ss_softmax_rows(void* scores, int64_t rows, int64_t cols, float scale, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, softmax_rows_launch, scores, rows, cols, scale, (hipStream_t)stream);
+}
+int ss_transpose(const void* in, void* out, int64_t rows, int64_t cols, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, transpose_launch, in, out, rows, cols, (hipStream_t)stream);
+}
+int ss_concat_channels(const void* a, const void* b, void* out, int64_t rows, int64_t c1, int64_t c2, int dtype,
+                       void* stream) {
+    return SS_DISPATCH(dtype, concat_channels_launch, a, b, out, rows, c1, c2, (hipStream_t)stream);
+}
+int ss_layout_nchw_nhwc(const void* in, void* out, int64_t batch, int64_t channels, int64_t hw, int64_t cpad,
+                        int to_nhwc, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, layout_launch, in, out, batch, channels, hw, cpad, to_nhwc, (hipStream_t)stream);
+}
+int ss_euler_scale_dup(const void* x, void* xin, int64_t n, float sigma, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, euler_scale_dup_launch, x, xin, n, sigma, (hipStream_t)stream);
+}
+int ss_euler_cfg_step(void* x, const void* eps, int64_t n, float guidance, float sigma, float sigma_next, int dtype,
+                      void* stream) {
+    return SS_DISPATCH(dtype, euler_cfg_step_launch, x, eps, n, guidance, sigma, sigma_next, (hipStream_t)stream);
+}
+int ss_image_to_u8(const void* in, void* out_u8, int64_t pixels, int64_t cpad, int dtype, void* stream) {
+    return SS_DISPATCH(dtype, image_to_u8_launch, in, out_u8, pixels, cpad, (hipStream_t)stream);
+}
+
+}  // extern "C"

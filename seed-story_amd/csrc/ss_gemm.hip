@@ -43,9 +43,13 @@ struct GemmArgs {
     int M, N, K;
     int64_t lda, ldw, ldc, ldr;
     int epi;
+    // per-(batch, n) additive vector (the ResBlock's projected time embedding): rowvec[m / rows_per_batch][n]
+    const void* rowvec; int rows_per_batch;
+    // implicit-GEMM 3x3 convolution over an NHWC tensor (A = [B, H, W, Cin]); K = 9 * Cin
+    int conv_H, conv_W, conv_Cin, conv_stride, conv_up, conv_Ho, conv_Wo;
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     constexpr int V = Tr<T>::kVec;
     constexpr int BK = 8 * V;            // 8 packs per tile row
@@ -76,6 +80,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[PA], rw[PW];
+    // conv mode: this thread's PA tile rows are fixed for the whole K loop -> decode (b, oy, ox) once
+    int cb[PA], cy[PA], cx[PA];
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = m_blk + ((tid + i * 256) >> 3);
+            const int hw = g.conv_Ho * g.conv_Wo;
+            cb[i] = m / hw;
+            const int rem = m - cb[i] * hw;
+            cy[i] = rem / g.conv_Wo;
+            cx[i] = rem - cy[i] * g.conv_Wo;
+        }
+    }
     auto load_tile = [&](int t) {
         const int k0 = t * BK;
 #pragma unroll
@@ -83,7 +100,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
             const int p = tid + i * 256;
             const int r = p >> 3, c = p & 7;
             const int m = m_blk + r, k = k0 + c * V;
-            ra[i] = (p < BM * 8 && m < M && k < K) ? ld16(A + (int64_t)m * g.lda + k) : make_uint4(0, 0, 0, 0);
+            if constexpr (CONV) {
+                // k -> (tap, ci); tap -> (dy, dx); zero padding 1; optional nearest 2x upsample of the input
+                const int tap = k / g.conv_Cin, ci = k - tap * g.conv_Cin;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                int iy = cy[i] * g.conv_stride + dy, ix = cx[i] * g.conv_stride + dx;
+                const int Hin = g.conv_up ? 2 * g.conv_H : g.conv_H, Win = g.conv_up ? 2 * g.conv_W : g.conv_W;
+                const bool ok = p < BM * 8 && m < M && k < K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+                if (g.conv_up) { iy >>= 1; ix >>= 1; }
+                ra[i] = ok ? ld16(A + (((int64_t)cb[i] * g.conv_H + iy) * g.conv_W + ix) * g.conv_Cin + ci)
+                           : make_uint4(0, 0, 0, 0);
+            } else {
+                ra[i] = (p < BM * 8 && m < M && k < K) ? ld16(A + (int64_t)m * g.lda + k) : make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
@@ -159,11 +188,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
             const int m = m_blk + wm * TM + j * 16 + l15;
             if (m >= M) continue;
             float v[4];
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g.rowvec) {
+                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[i][j][r] + bv[r];
                 if (g.epi & SS_EPI_GELU) t = gelu_erf(Tr<T>::rnd(t));  // Linear output is rounded, then GELU
                 v[r] = Tr<T>::rnd(t);
+                if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);   // h = conv(x) + temb[:, :, None, None]
             }
             if (g.epi & SS_EPI_RESIDUAL) {
 #pragma unroll
@@ -183,9 +219,21 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int LS = 8 * V + V;
     const size_t lds = (size_t)(BM + BN) * LS * sizeof(T);
     dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, s, g);
+    if (g.conv_Cin > 0)
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, true>), grid, dim3(256), lds, s, g);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, false>), grid, dim3(256), lds, s, g);
     SS_LAUNCH_CHECK("gemm");
     return SS_OK;
+}
+
+static int pick_cfg(int64_t M, int64_t N) {
+    const int force = tuning_get("gemm_cfg", 0);
+    if (force) return force;
+    const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+    if (M <= 128) return 3;          // weight streaming: many narrow-N blocks
+    if (big_blocks >= 200) return 1;
+    return 2;
 }
 
 template <typename T>
@@ -201,14 +249,35 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.residual = residual;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
-    const int force = tuning_get("gemm_cfg", 0);
-    const int64_t big_blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128);
-    int cfg;
-    if (force) cfg = force;
-    else if (M <= 128) cfg = 3;                 // weight streaming: many narrow-N blocks
-    else if (big_blocks >= 200) cfg = 1;
-    else cfg = 2;
-    switch (cfg) {
+    g.rowvec = nullptr; g.rows_per_batch = 1;
+    g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
+    switch (pick_cfg(M, N)) {
+        case 1: return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
+        case 2: return gemm_launch_cfg<T, 64, 64, 2, 2>(g, s);
+        default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
+    }
+}
+
+// 3x3 convolution, padding 1, stride 1|2, optional fused nearest-2x upsample of the input, NHWC:
+// x [B, H, W, Cin] -> y [B, Ho, Wo, Cout];  w [Cout, 9*Cin] with k = (ky*3 + kx)*Cin + ci.
+template <typename T>
+int conv3x3_launch(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t Wd, int64_t Cin, int64_t Cout,
+                   int64_t stride, int64_t up, const void* bias, const void* rowvec, const void* residual, int epi,
+                   hipStream_t s) {
+    constexpr int V = Tr<T>::kVec;
+    SS_REQUIRE(Cin % V == 0, "conv3x3: Cin=%lld must be a multiple of %d (pad the channels)", (long long)Cin, V);
+    SS_REQUIRE((stride == 1 || stride == 2) && !(up && stride != 1), "conv3x3: unsupported stride/upsample");
+    const int64_t Hin = up ? 2 * H : H, Win = up ? 2 * Wd : Wd;
+    const int64_t Ho = (Hin + 2 - 3) / stride + 1, Wo = (Win + 2 - 3) / stride + 1;
+    GemmArgs g;
+    g.A = x; g.W = w; g.C = y; g.bias = bias; g.residual = residual;
+    g.M = (int)(B * Ho * Wo); g.N = (int)Cout; g.K = (int)(9 * Cin);
+    g.lda = 0; g.ldw = 9 * Cin; g.ldc = Cout; g.ldr = Cout; g.epi = epi;
+    g.rowvec = rowvec; g.rows_per_batch = (int)(Ho * Wo);
+    g.conv_H = (int)H; g.conv_W = (int)Wd; g.conv_Cin = (int)Cin; g.conv_stride = (int)stride; g.conv_up = (int)up;
+    g.conv_Ho = (int)Ho; g.conv_Wo = (int)Wo;
+    if (g.M == 0) return SS_OK;
+    switch (pick_cfg(g.M, g.N)) {
         case 1: return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
         case 2: return gemm_launch_cfg<T, 64, 64, 2, 2>(g, s);
         default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
@@ -221,6 +290,14 @@ int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_
 }
 
 }  // namespace ss
+
+extern "C" int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, int64_t W_, int64_t Cin,
+                          int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
+                          const void* residual, int dtype, void* stream) {
+    const int epi = (bias ? SS_EPI_BIAS : 0) | (residual ? SS_EPI_RESIDUAL : 0);
+    return SS_DISPATCH(dtype, ss::conv3x3_launch, x, w, y, batch, H, W_, Cin, Cout, stride, upsample2x, bias, rowvec,
+                       residual, epi, (hipStream_t)stream);
+}
 
 extern "C" int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int64_t ldw, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue,

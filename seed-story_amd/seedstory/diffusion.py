@@ -1,0 +1,604 @@
+"""MI355X-native SDXL de-tokenizer: stand-ins for the four diffusers classes the reference
+instantiates (``src/inference/gen_george.py:10,60-64``; pipeline built at
+``src/models_ipa/adapter_modules.py:369-375`` and called at ``:455-466``):
+
+    EulerDiscreteScheduler.from_pretrained(path, subfolder="scheduler")
+    AutoencoderKL.from_pretrained(path, subfolder="vae")
+    UNet2DConditionModel.from_pretrained(path, subfolder="unet")
+    StableDiffusionXLPipeline(vae=, unet=, scheduler=, tokenizer=None, text_encoder=None, ...)
+
+diffusers itself is absent from this image.  The modules keep the diffusers parameter names (so
+``diffusion_pytorch_model.safetensors`` and the de-tokenizer checkpoint's ``unet.*`` keys load with
+``load_state_dict``) and run entirely on the HIP kernels of libseedstory_hip.so: activations are NHWC,
+3x3 convolutions are implicit GEMMs on the matrix cores (``ss_conv3x3``: fused bias / time-embedding /
+residual / nearest-2x upsample), GroupNorm+SiLU, fused-QKV flash attention, GEGLU, and the Euler/CFG
+update are hand-written kernels.  No torch compute on the device, no CPU path.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+SDXL_BASE_UNET = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+                      transformer_layers=(0, 2, 10), num_heads=(5, 10, 20), cross_attention_dim=2048,
+                      addition_time_embed_dim=256, pooled_dim=1280, norm_groups=32)
+SDXL_BASE_VAE = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                     norm_groups=32, scaling_factor=0.13025)
+
+
+# ---- parameter tree with diffusers key names ----------------------------------------------------------
+
+def _unet_shapes(c):
+    s = {}
+    boc = c["block_out_channels"]
+    temb = boc[0] * 4
+    xdim = c["cross_attention_dim"]
+
+    def lin(n, o, i, bias=True):
+        s[n + ".weight"] = (o, i)
+        if bias:
+            s[n + ".bias"] = (o,)
+
+    def conv(n, o, i, k):
+        s[n + ".weight"] = (o, i, k, k)
+        s[n + ".bias"] = (o,)
+
+    def norm(n, ch):
+        s[n + ".weight"] = (ch,)
+        s[n + ".bias"] = (ch,)
+
+    def resnet(n, i, o):
+        norm(n + ".norm1", i); conv(n + ".conv1", o, i, 3); lin(n + ".time_emb_proj", o, temb)
+        norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", o, i, 1)
+
+    def transformer(n, ch, layers):
+        norm(n + ".norm", ch); lin(n + ".proj_in", ch, ch)
+        for k in range(layers):
+            b = n + ".transformer_blocks.%d" % k
+            norm(b + ".norm1", ch)
+            for pn in ("to_q", "to_k", "to_v"):
+                lin(b + ".attn1." + pn, ch, ch, bias=False)
+            lin(b + ".attn1.to_out.0", ch, ch)
+            norm(b + ".norm2", ch)
+            lin(b + ".attn2.to_q", ch, ch, bias=False)
+            lin(b + ".attn2.to_k", ch, xdim, bias=False)
+            lin(b + ".attn2.to_v", ch, xdim, bias=False)
+            lin(b + ".attn2.to_out.0", ch, ch)
+            norm(b + ".norm3", ch)
+            lin(b + ".ff.net.0.proj", 8 * ch, ch)
+            lin(b + ".ff.net.2", ch, 4 * ch)
+        lin(n + ".proj_out", ch, ch)
+
+    conv("conv_in", boc[0], c["in_channels"], 3)
+    lin("time_embedding.linear_1", temb, boc[0]); lin("time_embedding.linear_2", temb, temb)
+    lin("add_embedding.linear_1", temb, 6 * c["addition_time_embed_dim"] + c["pooled_dim"])
+    lin("add_embedding.linear_2", temb, temb)
+    L = c["layers_per_block"]
+    ch = boc[0]
+    skips = [ch]
+    for i, o in enumerate(boc):
+        for j in range(L):
+            resnet("down_blocks.%d.resnets.%d" % (i, j), ch, o)
+            ch = o
+            if c["transformer_layers"][i]:
+                transformer("down_blocks.%d.attentions.%d" % (i, j), o, c["transformer_layers"][i])
+            skips.append(ch)
+        if i < len(boc) - 1:
+            conv("down_blocks.%d.downsamplers.0.conv" % i, o, o, 3)
+            skips.append(ch)
+    resnet("mid_block.resnets.0", ch, ch)
+    transformer("mid_block.attentions.0", ch, c["transformer_layers"][-1])
+    resnet("mid_block.resnets.1", ch, ch)
+    for i, o in enumerate(reversed(boc)):
+        tl = list(reversed(c["transformer_layers"]))[i]
+        for j in range(L + 1):
+            sk = skips.pop()
+            resnet("up_blocks.%d.resnets.%d" % (i, j), ch + sk, o)
+            ch = o
+            if tl:
+                transformer("up_blocks.%d.attentions.%d" % (i, j), o, tl)
+        if i < len(boc) - 1:
+            conv("up_blocks.%d.upsamplers.0.conv" % i, o, o, 3)
+    norm("conv_norm_out", ch)
+    conv("conv_out", c["out_channels"], ch, 3)
+    return s
+
+
+def _vae_shapes(c):
+    s = {}
+    boc = c["block_out_channels"]
+
+    def conv(n, o, i, k):
+        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
+
+    def norm(n, ch):
+        s[n + ".weight"] = (ch,); s[n + ".bias"] = (ch,)
+
+    def resnet(n, i, o):
+        norm(n + ".norm1", i); conv(n + ".conv1", o, i, 3); norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", o, i, 1)
+
+    lc = c["latent_channels"]
+    conv("post_quant_conv", lc, lc, 1)
+    top = boc[-1]
+    conv("decoder.conv_in", top, lc, 3)
+    resnet("decoder.mid_block.resnets.0", top, top)
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", top)
+    for pn in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[a + "." + pn + ".weight"] = (top, top); s[a + "." + pn + ".bias"] = (top,)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    ch = top
+    for i, o in enumerate(reversed(boc)):
+        for j in range(c["layers_per_block"] + 1):
+            resnet("decoder.up_blocks.%d.resnets.%d" % (i, j), ch, o)
+            ch = o
+        if i < len(boc) - 1:
+            conv("decoder.up_blocks.%d.upsamplers.0.conv" % i, o, o, 3)
+    norm("decoder.conv_norm_out", ch)
+    conv("decoder.conv_out", c["out_channels"], ch, 3)
+    return s
+
+
+class _Node(nn.Module):
+    """Bare module used to grow a parameter tree whose state_dict keys equal the diffusers names."""
+
+
+def _grow(root, shapes):
+    for key, shp in shapes.items():
+        parts = key.split(".")
+        m = root
+        for part in parts[:-1]:
+            if part not in m._modules:
+                m.add_module(part, _Node())
+            m = m._modules[part]
+        m.register_parameter(parts[-1], nn.Parameter(torch.empty(*shp), requires_grad=False))
+
+
+def _init_synthetic(module, seed):
+    for i, (name, prm) in enumerate(module.named_parameters()):
+        if prm.dim() == 1:
+            prm.data.fill_(1.0 if name.endswith("weight") else 0.0)
+        else:
+            fan_in = int(np.prod(prm.shape[1:]))
+            if prm.is_cuda:
+                prm.data.normal_(0.0, 1.0 / math.sqrt(fan_in))
+            else:
+                g = torch.Generator().manual_seed(seed * 7919 + i)
+                prm.data.copy_(torch.randn(prm.shape, generator=g) / math.sqrt(fan_in))
+    return module
+
+
+def _sig(module):
+    p0 = next(module.parameters())
+    return (p0.data_ptr(), p0._version, p0.dtype, str(p0.device), sum(p._version for p in module.parameters()))
+
+
+def _conv_w(w, cpad=None):
+    """[Co, Ci, 3, 3] -> [Co, 9 * Ci(pad)] with k = (ky*3 + kx) * Ci + ci  (host-side re-layout, once)."""
+    co, ci = w.shape[0], w.shape[1]
+    cp = ci if cpad is None else cpad
+    t = torch.zeros(co, 3, 3, cp, dtype=w.dtype, device=w.device)
+    t[..., :ci] = w.permute(0, 2, 3, 1)
+    return t.reshape(co, 9 * cp).contiguous()
+
+
+def timestep_embedding(t, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0), fp32 on the host
+    (a 1x320 vector per denoising step: scalar pre-processing, not device work)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = t.float().reshape(-1)[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class _Sample:
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+# ---- UNet ------------------------------------------------------------------------------------------------
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, config=None):
+        super().__init__()
+        self.cfg = dict(SDXL_BASE_UNET if config is None else config)
+        _grow(self, _unet_shapes(self.cfg))
+        self._prep = None
+        self._prep_sig = None
+
+    @property
+    def config(self):
+        return self.cfg
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, "config.json")) as f:
+            jc = json.load(f)
+        tl = jc.get("transformer_layers_per_block", 1)
+        boc = tuple(jc["block_out_channels"])
+        types = jc.get("down_block_types", ())
+        tl = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * len(boc)
+        tl = tuple(t if "CrossAttn" in types[i] else 0 for i, t in enumerate(tl)) if types else tl
+        heads = jc.get("attention_head_dim", 8)
+        heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(boc)
+        cfg = dict(in_channels=jc.get("in_channels", 4), out_channels=jc.get("out_channels", 4), block_out_channels=boc,
+                   layers_per_block=jc.get("layers_per_block", 2), transformer_layers=tl, num_heads=heads,
+                   cross_attention_dim=jc.get("cross_attention_dim", 2048),
+                   addition_time_embed_dim=jc.get("addition_time_embed_dim", 256),
+                   pooled_dim=jc.get("projection_class_embeddings_input_dim", 2816) - 6 * jc.get("addition_time_embed_dim", 256),
+                   norm_groups=jc.get("norm_num_groups", 32))
+        m = cls(cfg)
+        from safetensors.torch import load_file
+        sd = {}
+        for fn in sorted(os.listdir(folder)):
+            if fn.endswith(".safetensors") and "fp16" not in fn or fn == "diffusion_pytorch_model.fp16.safetensors" and not sd:
+                sd.update(load_file(os.path.join(folder, fn)))
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        print("unet: missing keys:", len(missing), "unexpected keys:", len(unexpected))
+        return m.to(torch_dtype) if torch_dtype is not None else m
+
+    def init_synthetic(self, seed=0):
+        _init_synthetic(self, seed)
+        self._prep = None
+        return self
+
+    # -- weight preparation (once per dtype/device/version) -------------------------------------------------
+    def _prepare(self):
+        sig = _sig(self)
+        if self._prep is not None and self._prep_sig == sig:
+            return self._prep
+        sd = {k: v.data for k, v in self.named_parameters()}
+        P = {}
+        for k, v in sd.items():
+            if v.dim() == 4 and v.shape[-1] == 3:
+                cpad = 8 if v.shape[1] < 8 else None
+                P[k] = _conv_w(v, cpad)
+            elif v.dim() == 4:
+                P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()
+            else:
+                P[k] = v
+        # fused projections: self-attention q|k|v, cross-attention k|v
+        for k in list(sd.keys()):
+            if k.endswith("attn1.to_q.weight"):
+                b = k[:-len("to_q.weight")]
+                P[b + "qkv"] = torch.cat([sd[b + "to_q.weight"], sd[b + "to_k.weight"], sd[b + "to_v.weight"]], 0).contiguous()
+            if k.endswith("attn2.to_k.weight"):
+                b = k[:-len("to_k.weight")]
+                P[b + "kv"] = torch.cat([sd[b + "to_k.weight"], sd[b + "to_v.weight"]], 0).contiguous()
+        self._prep, self._prep_sig = P, sig
+        return P
+
+    # -- forward ----------------------------------------------------------------------------------------------
+    def _resnet(self, P, n, x, B, H, W, temb_act, groups, eps=1e-5):
+        h = ops.groupnorm(x, P[n + ".norm1.weight"], P[n + ".norm1.bias"], B, groups, eps, silu=True)
+        tp = None
+        if temb_act is not None:
+            tp = ops.gemm(temb_act, P[n + ".time_emb_proj.weight"], bias=P[n + ".time_emb_proj.bias"])
+        h, _, _ = ops.conv3x3(h, P[n + ".conv1.weight"], B, H, W, bias=P[n + ".conv1.bias"], rowvec=tp)
+        h = ops.groupnorm(h, P[n + ".norm2.weight"], P[n + ".norm2.bias"], B, groups, eps, silu=True)
+        sc = x
+        if (n + ".conv_shortcut.weight") in P:
+            sc = ops.gemm(x, P[n + ".conv_shortcut.weight"], bias=P[n + ".conv_shortcut.bias"])
+        h, _, _ = ops.conv3x3(h, P[n + ".conv2.weight"], B, H, W, bias=P[n + ".conv2.bias"], residual=sc)
+        return h
+
+    def _transformer(self, P, n, x, B, HW, ctx2d, Lctx, heads, layers, groups):
+        C = x.shape[1]
+        h = ops.groupnorm(x, P[n + ".norm.weight"], P[n + ".norm.bias"], B, groups, 1e-6, silu=False)
+        h = ops.gemm(h, P[n + ".proj_in.weight"], bias=P[n + ".proj_in.bias"])
+        for k in range(layers):
+            b = n + ".transformer_blocks.%d" % k
+            y = ops.layernorm(h, P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5)
+            qkv = ops.gemm(y, P[b + ".attn1.qkv"])
+            a = ops.attention_qkv_packed(qkv, B, HW, heads)
+            h = ops.gemm(a, P[b + ".attn1.to_out.0.weight"], bias=P[b + ".attn1.to_out.0.bias"], residual=h)
+            y = ops.layernorm(h, P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5)
+            q = ops.gemm(y, P[b + ".attn2.to_q.weight"])
+            kv = ops.gemm(ctx2d, P[b + ".attn2.kv"])
+            a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
+            h = ops.gemm(a, P[b + ".attn2.to_out.0.weight"], bias=P[b + ".attn2.to_out.0.bias"], residual=h)
+            y = ops.layernorm(h, P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5)
+            g = ops.gemm(y, P[b + ".ff.net.0.proj.weight"], bias=P[b + ".ff.net.0.proj.bias"])
+            h = ops.gemm(ops.geglu(g), P[b + ".ff.net.2.weight"], bias=P[b + ".ff.net.2.bias"], residual=h)
+        return ops.gemm(h, P[n + ".proj_out.weight"], bias=P[n + ".proj_out.bias"], residual=x)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **kw):
+        """sample [B,4,h,w] NCHW (diffusers convention) -> eps [B,4,h,w]."""
+        c = self.cfg
+        P = self._prepare()
+        dt, dev = sample.dtype, sample.device
+        B, _, H, W = sample.shape
+        boc, G, L = c["block_out_channels"], c["norm_groups"], c["layers_per_block"]
+        # time + added ("text_time") conditioning: sinusoids on the host, MLPs on the device
+        t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).expand(B)
+        temb = timestep_embedding(t, boc[0]).to(device=dev, dtype=dt)
+        emb = ops.gemm(ops.silu(ops.gemm(temb, P["time_embedding.linear_1.weight"], bias=P["time_embedding.linear_1.bias"])),
+                       P["time_embedding.linear_2.weight"], bias=P["time_embedding.linear_2.bias"])
+        tid = timestep_embedding(added_cond_kwargs["time_ids"].flatten().cpu(), c["addition_time_embed_dim"])
+        add = torch.cat([added_cond_kwargs["text_embeds"].to(dt), tid.reshape(B, -1).to(device=dev, dtype=dt)], dim=-1).contiguous()
+        emb = ops.gemm(ops.silu(ops.gemm(add, P["add_embedding.linear_1.weight"], bias=P["add_embedding.linear_1.bias"])),
+                       P["add_embedding.linear_2.weight"], bias=P["add_embedding.linear_2.bias"], residual=emb)
+        temb_act = ops.silu(emb)                                            # F.silu(temb) feeds every ResBlock
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        Lctx = ctx.shape[1]
+        ctx2d = ctx.view(B * Lctx, -1)
+
+        x = ops.nchw_to_nhwc(sample.contiguous(), 8)                       # 4 -> 8 zero-padded channels
+        h, _, _ = ops.conv3x3(x, P["conv_in.weight"], B, H, W, bias=P["conv_in.bias"])
+        skips = [(h, H, W)]
+        for i in range(len(boc)):
+            for j in range(L):
+                h = self._resnet(P, "down_blocks.%d.resnets.%d" % (i, j), h, B, H, W, temb_act, G)
+                if c["transformer_layers"][i]:
+                    h = self._transformer(P, "down_blocks.%d.attentions.%d" % (i, j), h, B, H * W, ctx2d, Lctx,
+                                          c["num_heads"][i], c["transformer_layers"][i], G)
+                skips.append((h, H, W))
+            if i < len(boc) - 1:
+                n = "down_blocks.%d.downsamplers.0.conv" % i
+                h, H, W = ops.conv3x3(h, P[n + ".weight"], B, H, W, stride=2, bias=P[n + ".bias"])
+                skips.append((h, H, W))
+        h = self._resnet(P, "mid_block.resnets.0", h, B, H, W, temb_act, G)
+        h = self._transformer(P, "mid_block.attentions.0", h, B, H * W, ctx2d, Lctx, c["num_heads"][-1],
+                              c["transformer_layers"][-1], G)
+        h = self._resnet(P, "mid_block.resnets.1", h, B, H, W, temb_act, G)
+        for i in range(len(boc)):
+            ri = len(boc) - 1 - i
+            for j in range(L + 1):
+                sk, _, _ = skips.pop()
+                h = ops.concat_channels(h, sk)                               # torch.cat([h, skip], dim=1)
+                h = self._resnet(P, "up_blocks.%d.resnets.%d" % (i, j), h, B, H, W, temb_act, G)
+                if c["transformer_layers"][ri]:
+                    h = self._transformer(P, "up_blocks.%d.attentions.%d" % (i, j), h, B, H * W, ctx2d, Lctx,
+                                          c["num_heads"][ri], c["transformer_layers"][ri], G)
+            if i < len(boc) - 1:
+                n = "up_blocks.%d.upsamplers.0.conv" % i
+                h, H, W = ops.conv3x3(h, P[n + ".weight"], B, H, W, upsample=True, bias=P[n + ".bias"])
+        h = ops.groupnorm(h, P["conv_norm_out.weight"], P["conv_norm_out.bias"], B, G, 1e-5, silu=True)
+        o, _, _ = ops.conv3x3(h, P["conv_out.weight"], B, H, W, bias=P["conv_out.bias"])
+        out = ops.nhwc_to_nchw(o, B, c["out_channels"], H, W)
+        return _Sample(out) if return_dict else (out,)
+
+
+# ---- VAE decoder ---------------------------------------------------------------------------------------------
+
+class _VaeConfig:
+    def __init__(self, scaling_factor, force_upcast=False):
+        self.scaling_factor = scaling_factor
+        self.force_upcast = force_upcast
+
+
+class AutoencoderKL(nn.Module):
+    """Decoder half only (the story path never encodes).  Runs in the module dtype: bf16 has the
+    range fp16 lacked, so diffusers' fp32 ``force_upcast`` of the fp16 VAE is not needed."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.cfg = dict(SDXL_BASE_VAE if config is None else config)
+        _grow(self, _vae_shapes(self.cfg))
+        self.config = _VaeConfig(self.cfg["scaling_factor"])
+        self._prep = None
+        self._prep_sig = None
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, "config.json")) as f:
+            jc = json.load(f)
+        cfg = dict(latent_channels=jc.get("latent_channels", 4), out_channels=jc.get("out_channels", 3),
+                   block_out_channels=tuple(jc["block_out_channels"]), layers_per_block=jc.get("layers_per_block", 2),
+                   norm_groups=jc.get("norm_num_groups", 32), scaling_factor=jc.get("scaling_factor", 0.13025))
+        m = cls(cfg)
+        from safetensors.torch import load_file
+        sd = {}
+        for fn in sorted(os.listdir(folder)):
+            if fn.endswith(".safetensors") and not sd:
+                sd.update(load_file(os.path.join(folder, fn)))
+        # older checkpoints name the mid-block attention projections query/key/value/proj_attn
+        ren = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+        sd = {_rename(k, ren): v for k, v in sd.items()}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        print("vae: missing keys:", len(missing), "unexpected keys (encoder etc.):", len(unexpected))
+        return m.to(torch_dtype) if torch_dtype is not None else m
+
+    def init_synthetic(self, seed=0):
+        _init_synthetic(self, seed)
+        self._prep = None
+        return self
+
+    def _prepare(self):
+        sig = _sig(self)
+        if self._prep is not None and self._prep_sig == sig:
+            return self._prep
+        P = {}
+        for k, v in self.named_parameters():
+            v = v.data
+            if v.dim() == 4 and v.shape[-1] == 3:
+                P[k] = _conv_w(v, 8 if v.shape[1] < 8 else None)
+            elif v.dim() == 4:
+                P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()
+            else:
+                P[k] = v
+        # post_quant_conv (1x1, 4 -> 4) consumes the 8-channel padded latent layout
+        w = P["post_quant_conv.weight"]
+        wp = torch.zeros(8, 8, dtype=w.dtype, device=w.device)
+        wp[:w.shape[0], :w.shape[1]] = w
+        bp = torch.zeros(8, dtype=w.dtype, device=w.device)
+        bp[:w.shape[0]] = P["post_quant_conv.bias"]
+        P["post_quant_conv.weight"], P["post_quant_conv.bias"] = wp, bp
+        self._prep, self._prep_sig = P, sig
+        return P
+
+    def _resnet(self, P, n, x, B, H, W, G):
+        h = ops.groupnorm(x, P[n + ".norm1.weight"], P[n + ".norm1.bias"], B, G, 1e-6, silu=True)
+        h, _, _ = ops.conv3x3(h, P[n + ".conv1.weight"], B, H, W, bias=P[n + ".conv1.bias"])
+        h = ops.groupnorm(h, P[n + ".norm2.weight"], P[n + ".norm2.bias"], B, G, 1e-6, silu=True)
+        sc = x
+        if (n + ".conv_shortcut.weight") in P:
+            sc = ops.gemm(x, P[n + ".conv_shortcut.weight"], bias=P[n + ".conv_shortcut.bias"])
+        h, _, _ = ops.conv3x3(h, P[n + ".conv2.weight"], B, H, W, bias=P[n + ".conv2.bias"], residual=sc)
+        return h
+
+    @torch.no_grad()
+    def decode_nhwc(self, latents_scaled, prescale=1.0):
+        """latents [B,4,h,w] (times `prescale`, i.e. pass 1/scaling_factor for raw latents) -> NHWC image
+        tensor [B*H*W, 8] in [-1,1] (channels 3..7 are zero padding)."""
+        c = self.cfg
+        P = self._prepare()
+        G, boc = c["norm_groups"], c["block_out_channels"]
+        B, _, H, W = latents_scaled.shape
+        z = ops.nchw_to_nhwc(latents_scaled.contiguous(), 8)
+        pq = P["post_quant_conv.weight"]
+        if prescale != 1.0:
+            key = "post_quant_conv.weight@%r" % prescale
+            if key not in P:
+                P[key] = (pq.float() * prescale).to(pq.dtype)
+            pq = P[key]
+        z = ops.gemm(z, pq, bias=P["post_quant_conv.bias"])
+        h, _, _ = ops.conv3x3(z, P["decoder.conv_in.weight"], B, H, W, bias=P["decoder.conv_in.bias"])
+        h = self._resnet(P, "decoder.mid_block.resnets.0", h, B, H, W, G)
+        a = "decoder.mid_block.attentions.0"
+        C = h.shape[1]
+        y = ops.groupnorm(h, P[a + ".group_norm.weight"], P[a + ".group_norm.bias"], B, G, 1e-6, silu=False)
+        q = ops.gemm(y, P[a + ".to_q.weight"], bias=P[a + ".to_q.bias"])
+        k = ops.gemm(y, P[a + ".to_k.weight"], bias=P[a + ".to_k.bias"])
+        v = ops.gemm(y, P[a + ".to_v.weight"], bias=P[a + ".to_v.bias"])
+        outs = []
+        T = H * W
+        for b in range(B):   # single head of dim C (512): materialised scores like the reference's eager path
+            qb, kb, vb = q[b * T:(b + 1) * T], k[b * T:(b + 1) * T], v[b * T:(b + 1) * T]
+            if C <= 128:
+                outs.append(ops.attention(qb.unsqueeze(0).contiguous(), kb.unsqueeze(0).contiguous(),
+                                          vb.unsqueeze(0).contiguous(), 1)[0])
+            else:
+                s = ops.gemm(qb.contiguous(), kb.contiguous())               # [T, T]
+                ops.softmax_rows_(s, 1.0 / math.sqrt(C))
+                outs.append(ops.gemm(s, ops.transpose(vb.contiguous())))     # P @ V
+        o = torch.cat(outs, dim=0) if B > 1 else outs[0]
+        h = ops.gemm(o.contiguous(), P[a + ".to_out.0.weight"], bias=P[a + ".to_out.0.bias"], residual=h)
+        h = self._resnet(P, "decoder.mid_block.resnets.1", h, B, H, W, G)
+        for i in range(len(boc)):
+            for j in range(c["layers_per_block"] + 1):
+                h = self._resnet(P, "decoder.up_blocks.%d.resnets.%d" % (i, j), h, B, H, W, G)
+            if i < len(boc) - 1:
+                n = "decoder.up_blocks.%d.upsamplers.0.conv" % i
+                h, H, W = ops.conv3x3(h, P[n + ".weight"], B, H, W, upsample=True, bias=P[n + ".bias"])
+        h = ops.groupnorm(h, P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"], B, G, 1e-6, silu=True)
+        # conv_out to 3 channels, written into an 8-channel padded NHWC tensor
+        w = P["decoder.conv_out.weight"]
+        wp = torch.zeros(8, w.shape[1], dtype=w.dtype, device=w.device)
+        wp[:w.shape[0]] = w
+        bp = torch.zeros(8, dtype=w.dtype, device=w.device)
+        bp[:w.shape[0]] = P["decoder.conv_out.bias"]
+        img, _, _ = ops.conv3x3(h, wp, B, H, W, bias=bp)
+        return img, H, W
+
+    @torch.no_grad()
+    def decode(self, latents, return_dict=True):
+        """diffusers signature: latents are ALREADY divided by scaling_factor by the caller."""
+        img, H, W = self.decode_nhwc(latents)
+        B = latents.shape[0]
+        out = ops.nhwc_to_nchw(img, B, self.cfg["out_channels"], H, W)
+        return _Sample(out) if return_dict else (out,)
+
+
+def _rename(k, table):
+    for a, b in table.items():
+        k = k.replace(a, b)
+    return k
+
+
+# ---- scheduler + pipeline ----------------------------------------------------------------------------------------
+
+class EulerDiscreteScheduler:
+    """EulerDiscreteScheduler of SDXL-base: scaled-linear betas, 'leading' timestep spacing with
+    steps_offset, linearly interpolated sigmas, epsilon prediction, no churn."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 timestep_spacing="leading", steps_offset=1, prediction_type="epsilon", **kw):
+        assert beta_schedule == "scaled_linear" and prediction_type == "epsilon"
+        self.num_train_timesteps, self.steps_offset, self.timestep_spacing = num_train_timesteps, steps_offset, timestep_spacing
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
+        ac = np.cumprod(1.0 - betas)
+        self._sigmas_all = ((1 - ac) / ac) ** 0.5
+        self.timesteps = None
+        self.sigmas = None
+        self.init_noise_sigma = None
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kw):
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, "scheduler_config.json")) as f:
+            jc = json.load(f)
+        return cls(**{k: v for k, v in jc.items() if not k.startswith("_")})
+
+    def set_timesteps(self, n):
+        if self.timestep_spacing == "leading":
+            ratio = self.num_train_timesteps // n
+            ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        elif self.timestep_spacing == "linspace":
+            ts = np.linspace(0, self.num_train_timesteps - 1, n, dtype=np.float32)[::-1].copy()
+        else:
+            ratio = self.num_train_timesteps / n
+            ts = (np.arange(self.num_train_timesteps, 0, -ratio)).round().astype(np.float32) - 1
+        s = np.interp(ts, np.arange(0, len(self._sigmas_all)), self._sigmas_all)
+        self.sigmas = np.concatenate([s, [0.0]]).astype(np.float32)
+        self.timesteps = ts
+        mx = float(self.sigmas.max())
+        self.init_noise_sigma = mx if self.timestep_spacing in ("linspace", "trailing") else float((mx ** 2 + 1) ** 0.5)
+
+
+class _PipeOut:
+    def __init__(self, images):
+        self.images = images
+
+
+class StableDiffusionXLPipeline:
+    """The slice of diffusers' StableDiffusionXLPipeline that SDXLAdapter.generate uses (prompt embeds
+    supplied, no text encoders; adapter_modules.py:369-375,455-466)."""
+
+    def __init__(self, vae, unet, scheduler, tokenizer=None, tokenizer_2=None, text_encoder=None, text_encoder_2=None,
+                 **kw):
+        self.vae, self.unet, self.scheduler = vae, unet, scheduler
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds,
+                 guidance_scale=7.5, num_inference_steps=30, generator=None, height=1024, width=1024, latents=None,
+                 output_type="pil", **kw):
+        dev, dt = prompt_embeds.device, prompt_embeds.dtype
+        lh, lw = height // 8, width // 8
+        self.scheduler.set_timesteps(num_inference_steps)
+        sig, ts = self.scheduler.sigmas, self.scheduler.timesteps
+        if latents is None:
+            latents = torch.randn((1, 4, lh, lw), generator=generator, device=dev, dtype=dt)
+        x = (latents.to(device=dev, dtype=dt) * self.scheduler.init_noise_sigma).contiguous()
+        time_ids = torch.tensor([[height, width, 0, 0, height, width]] * 2, dtype=torch.float32)
+        ctx = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).contiguous()
+        pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0).contiguous()
+        cond = {"text_embeds": pooled, "time_ids": time_ids}
+        for i in range(num_inference_steps):
+            xin = ops.euler_scale_dup(x, float(sig[i])).view(2, 4, lh, lw)   # [uncond; cond] batch, x/sqrt(s^2+1)
+            eps = self.unet(xin, float(ts[i]), ctx, added_cond_kwargs=cond, return_dict=False)[0]
+            ops.euler_cfg_step_(x, eps.contiguous(), guidance_scale, float(sig[i]), float(sig[i + 1]))
+        if output_type == "latent":
+            return _PipeOut(x)
+        # latents / scaling_factor is folded into the 1x1 post_quant_conv weights (linear, exact in fp32)
+        img, H, W = self.vae.decode_nhwc(x.view(1, 4, lh, lw), prescale=1.0 / self.vae.config.scaling_factor)
+        u8 = ops.image_to_u8(img, H * W).view(H, W, 3)
+        if output_type == "pt":
+            return _PipeOut(u8)
+        from PIL import Image
+        return _PipeOut([Image.fromarray(u8.cpu().numpy())])

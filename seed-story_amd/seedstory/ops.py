@@ -186,3 +186,131 @@ def imgproc_argmax(logits, last_id, img_ids):
     check(lib().ss_imgproc_argmax(p(logits), logits.numel(), p(last), p(ids), ids.numel(), p(tok), dt(logits),
                                   stream()), "ss_imgproc_argmax")
     return tok
+
+
+# ---- SDXL de-tokenizer ops (NHWC activations: [B, H*W, C]) ------------------------------------------
+def conv3x3(x, w, B, H, W, stride=1, upsample=False, bias=None, rowvec=None, residual=None):
+    """x [B*H*W, Cin] (NHWC) -> [B*Ho*Wo, Cout]; w [Cout, 9*Cin] (tap-major, channel-minor)."""
+    _req(x); _req(w)
+    Cin = x.shape[-1]
+    Cout = w.shape[0]
+    Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
+    Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    y = torch.empty(B * Ho * Wo, Cout, dtype=x.dtype, device=x.device)
+    check(lib().ss_conv3x3(p(x), p(w), p(y), B, H, W, Cin, Cout, stride, int(upsample), p(bias), p(rowvec), p(residual),
+                           dt(x), stream()), "ss_conv3x3")
+    return y, Ho, Wo
+
+
+def groupnorm(x, gamma, beta, B, groups, eps, silu=False):
+    """x [B*HW, C] NHWC"""
+    _req(x)
+    C = x.shape[-1]
+    HW = x.shape[0] // B
+    y = torch.empty_like(x)
+    ws = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+    check(lib().ss_groupnorm(p(x), p(gamma), p(beta), p(y), p(ws), B, HW, C, groups, eps, int(silu), dt(x), stream()),
+          "ss_groupnorm")
+    return y
+
+
+def geglu(x):
+    _req(x)
+    rows, two_d = x.shape
+    out = torch.empty(rows, two_d // 2, dtype=x.dtype, device=x.device)
+    check(lib().ss_geglu(p(x), p(out), rows, two_d // 2, dt(x), stream()), "ss_geglu")
+    return out
+
+
+def silu(x):
+    _req(x)
+    y = torch.empty_like(x)
+    check(lib().ss_unary(p(x), p(y), x.numel(), 0, dt(x), stream()), "ss_unary")
+    return y
+
+
+def attention_qkv_packed(qkv, B, L, n_heads):
+    """Self-attention on a fused projection qkv [B*L, 3E] = [q | k | v] per token -> [B*L, E]."""
+    _req(qkv)
+    E = qkv.shape[1] // 3
+    hd = E // n_heads
+    out = torch.empty(B * L, E, dtype=qkv.dtype, device=qkv.device)
+    esz = qkv.element_size()
+    base = qkv.data_ptr()
+    check(lib().ss_attention(base, base + E * esz, base + 2 * E * esz, p(out), B, n_heads, L, L, hd, L * 3 * E, hd, 3 * E,
+                             L * 3 * E, hd, 3 * E, L * 3 * E, hd, 3 * E, L * E, hd, E, 1.0 / math.sqrt(hd), 0, dt(qkv),
+                             stream()), "ss_attention")
+    return out
+
+
+def attention_q_kvpacked(q, kv, B, Lq, Lk, n_heads):
+    """Cross-attention: q [B*Lq, E], kv [B*Lk, 2E] = [k | v] per context token -> [B*Lq, E]."""
+    _req(q); _req(kv)
+    E = q.shape[1]
+    hd = E // n_heads
+    out = torch.empty_like(q)
+    esz = q.element_size()
+    kb = kv.data_ptr()
+    check(lib().ss_attention(p(q), kb, kb + E * esz, p(out), B, n_heads, Lq, Lk, hd, Lq * E, hd, E, Lk * 2 * E, hd, 2 * E,
+                             Lk * 2 * E, hd, 2 * E, Lq * E, hd, E, 1.0 / math.sqrt(hd), 0, dt(q), stream()), "ss_attention")
+    return out
+
+
+def softmax_rows_(s, scale):
+    _req(s)
+    check(lib().ss_softmax_rows(p(s), s.shape[0], s.shape[1], scale, dt(s), stream()), "ss_softmax_rows")
+    return s
+
+
+def transpose(x):
+    _req(x)
+    R, Cc = x.shape
+    out = torch.empty(Cc, R, dtype=x.dtype, device=x.device)
+    check(lib().ss_transpose(p(x), p(out), R, Cc, dt(x), stream()), "ss_transpose")
+    return out
+
+
+def concat_channels(a, b):
+    _req(a); _req(b)
+    rows = a.shape[0]
+    out = torch.empty(rows, a.shape[1] + b.shape[1], dtype=a.dtype, device=a.device)
+    check(lib().ss_concat_channels(p(a), p(b), p(out), rows, a.shape[1], b.shape[1], dt(a), stream()),
+          "ss_concat_channels")
+    return out
+
+
+def nchw_to_nhwc(x, cpad):
+    _req(x)
+    B, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    out = torch.empty(B * HW, cpad, dtype=x.dtype, device=x.device)
+    check(lib().ss_layout_nchw_nhwc(p(x), p(out), B, Cc, HW, cpad, 1, dt(x), stream()), "ss_layout_nchw_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, B, C, H, W):
+    _req(x)
+    out = torch.empty(B, C, H, W, dtype=x.dtype, device=x.device)
+    check(lib().ss_layout_nchw_nhwc(p(x), p(out), B, C, H * W, x.shape[-1], 0, dt(x), stream()), "ss_layout_nchw_nhwc")
+    return out
+
+
+def euler_scale_dup(x, sigma):
+    _req(x)
+    xin = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(lib().ss_euler_scale_dup(p(x), p(xin), x.numel(), float(sigma), dt(x), stream()), "ss_euler_scale_dup")
+    return xin
+
+
+def euler_cfg_step_(x, eps, guidance, sigma, sigma_next):
+    _req(x); _req(eps)
+    check(lib().ss_euler_cfg_step(p(x), p(eps), x.numel(), float(guidance), float(sigma), float(sigma_next), dt(x),
+                                  stream()), "ss_euler_cfg_step")
+    return x
+
+
+def image_to_u8(x, pixels):
+    _req(x)
+    out = torch.empty(pixels, 3, dtype=torch.uint8, device=x.device)
+    check(lib().ss_image_to_u8(p(x), p(out), pixels, x.shape[-1], dt(x), stream()), "ss_image_to_u8")
+    return out

@@ -1,0 +1,220 @@
+"""GPU parity of the SDXL de-tokenizer half (conv3x3 implicit GEMM, GroupNorm, GEGLU, UNet, VAE decoder,
+Euler/CFG pipeline, ResamplerXLV2, SDXLAdapter.generate) against the CPU oracle (oracle/sdxl_oracle.py —
+restatement of the published diffusers semantics; parity unpinned at that boundary) on tiny configs, in
+fp32 (gate: 2e-4 relative) and bf16 (5e-2 relative: GroupNorm statistics / 3x3 convs in bf16 inputs)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sdxl_oracle as S
+import seedstory_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def nchw(y, B, H, W):
+    return y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 8, 16, 9, 7, 1, False), (1, 64, 96, 16, 16, 1, False),
+                                                   (2, 320, 64, 8, 8, 2, False), (1, 32, 40, 6, 5, 1, True),
+                                                   (1, 1920, 64, 8, 8, 1, False), (1, 128, 8, 33, 31, 1, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
+    from seedstory import ops
+    from seedstory.diffusion import _conv_w
+    x = synth.normal_like(1, (B, Ci, H, W), 1.0, dtype=dtype)
+    w = synth.normal_like(2, (Co, Ci, 3, 3), 1.0 / math.sqrt(9 * Ci), dtype=dtype)
+    b = synth.normal_like(3, (Co,), 0.5, dtype=dtype)
+    tv = synth.normal_like(4, (B, Co), 0.5, dtype=dtype)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xi, w.float(), b.float(), stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = synth.normal_like(5, (B, Co, Ho, Wo), 1.0, dtype=dtype)
+    y, ho, wo = ops.conv3x3(nhwc(x).to(DEV), _conv_w(w).to(DEV), B, H, W, stride=stride, upsample=up, bias=b.to(DEV))
+    assert (ho, wo) == (Ho, Wo)
+    tol = 2e-5 if dtype == torch.float32 else 5e-3
+    assert rel(nchw(y.cpu(), B, Ho, Wo), ref) < tol
+    y2, _, _ = ops.conv3x3(nhwc(x).to(DEV), _conv_w(w).to(DEV), B, H, W, stride=stride, upsample=up, bias=b.to(DEV),
+                           rowvec=tv.to(DEV), residual=nhwc(res).to(DEV))
+    ref2 = ref + tv.float()[:, :, None, None] + res.float()
+    assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 5, 7, 32), (1, 320, 16, 16, 32), (2, 128, 33, 9, 32), (1, 1920, 4, 4, 32)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groupnorm_silu(B, C, H, W, G, dtype):
+    from seedstory import ops
+    x = synth.normal_like(6, (B, C, H, W), 2.0, 0.5, dtype=dtype)
+    g = synth.normal_like(7, (C,), 0.1, 1.0, dtype=dtype)
+    b = synth.normal_like(8, (C,), 0.1, dtype=dtype)
+    for silu in (False, True):
+        ref = F.group_norm(x.float(), G, g.float(), b.float(), 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        y = ops.groupnorm(nhwc(x).to(DEV), g.to(DEV), b.to(DEV), B, G, 1e-5, silu=silu)
+        assert rel(nchw(y.cpu(), B, H, W), ref) < (2e-5 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_diffusion_ops(dtype):
+    from seedstory import ops
+    x = synth.normal_like(9, (37, 2 * 256), 1.5, dtype=dtype)
+    ref = x[:, :256].float() * F.gelu(x[:, 256:].float())
+    assert rel(ops.geglu(x.to(DEV)), ref) < (1e-6 if dtype == torch.float32 else 6e-3)
+    s = synth.normal_like(10, (19, 512), 3.0, dtype=dtype)
+    ref = torch.softmax(s.float() * 0.3, -1)
+    assert rel(ops.softmax_rows_(s.to(DEV), 0.3), ref) < (1e-6 if dtype == torch.float32 else 6e-3)
+    t = synth.normal_like(11, (45, 70), 1.0, dtype=dtype)
+    assert torch.equal(ops.transpose(t.to(DEV)).cpu(), t.t().contiguous())
+    a = synth.normal_like(12, (11, 64), 1.0, dtype=dtype)
+    b = synth.normal_like(13, (11, 24), 1.0, dtype=dtype)
+    assert torch.equal(ops.concat_channels(a.to(DEV), b.to(DEV)).cpu(), torch.cat([a, b], 1))
+    lat = synth.normal_like(14, (2, 4, 6, 5), 1.0, dtype=dtype)
+    nh = ops.nchw_to_nhwc(lat.to(DEV), 8)
+    assert torch.equal(nh[:, :4].cpu(), nhwc(lat)) and float(nh[:, 4:].abs().sum()) == 0
+    assert torch.equal(ops.nhwc_to_nchw(nh, 2, 4, 6, 5).cpu(), lat)
+    assert rel(ops.silu(a.to(DEV)), F.silu(a.float())) < (1e-6 if dtype == torch.float32 else 4e-3)
+    xs = ops.euler_scale_dup(lat.to(DEV), 3.0)
+    assert rel(xs[1], lat.float() / math.sqrt(10.0)) < (1e-6 if dtype == torch.float32 else 4e-3)
+    eps = synth.normal_like(15, (2, 2, 4, 6, 5), 1.0, dtype=dtype)
+    xd = lat.to(DEV).clone()
+    ops.euler_cfg_step_(xd, eps.to(DEV), 7.5, 3.0, 2.5)
+    e = eps[0].float() + 7.5 * (eps[1].float() - eps[0].float())
+    assert rel(xd, lat.float() + e * (2.5 - 3.0)) < (1e-6 if dtype == torch.float32 else 2e-2)
+    img = synth.normal_like(16, (30, 8), 0.8, dtype=dtype)
+    u8 = ops.image_to_u8(img.to(DEV), 30).cpu()
+    ref = ((img[:, :3].float() / 2 + 0.5).clamp(0, 1) * 255).round()
+    assert (u8.float() - ref).abs().max() <= 1
+
+
+def _unet(dtype):
+    from seedstory.diffusion import UNet2DConditionModel
+    c = S.TINY_UNET
+    wd = S.synth_weights(S.unet_shapes(c), 1)
+    m = UNet2DConditionModel(c)
+    missing, unexpected = m.load_state_dict(wd, strict=False)
+    assert not missing and not unexpected
+    return m.to(DEV, dtype), wd, c
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
+def test_unet_forward_tiny(dtype, tol):
+    m, wd, c = _unet(dtype)
+    x = synth.normal_like(5, (2, 4, 16, 16), 1.0)
+    ctx = synth.normal_like(6, (2, 8, 128), 1.0)
+    pooled = synth.normal_like(7, (2, 80), 1.0)
+    tid = torch.tensor([[128, 128, 0, 0, 128, 128]] * 2, dtype=torch.float32)
+    ref = S.unet_forward(wd, c, x, torch.tensor(801.0), ctx, pooled, tid)
+    y = m(x.to(DEV, dtype), 801.0, ctx.to(DEV, dtype), added_cond_kwargs={"text_embeds": pooled.to(DEV, dtype), "time_ids": tid}).sample
+    assert y.shape == ref.shape
+    assert rel(y, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
+def test_vae_decode_tiny(dtype, tol):
+    from seedstory.diffusion import AutoencoderKL
+    c = S.TINY_VAE
+    wd = S.synth_weights(S.vae_decoder_shapes(c), 2)
+    m = AutoencoderKL(c)
+    missing, unexpected = m.load_state_dict(wd, strict=False)
+    assert not missing and not unexpected
+    m = m.to(DEV, dtype)
+    lat = synth.normal_like(20, (1, 4, 12, 12), 1.0)
+    ref = S.vae_decode(wd, c, lat)
+    y = m.decode((lat / c["scaling_factor"]).to(DEV, dtype)).sample
+    assert rel(y, ref) < tol
+
+
+def test_vae_mid_attention_wide_head_path():
+    """head_dim > 128 (SDXL VAE: one head of 512) takes the materialised-softmax path."""
+    from seedstory.diffusion import AutoencoderKL
+    c = dict(S.TINY_VAE, block_out_channels=(32, 64, 64, 256))
+    wd = S.synth_weights(S.vae_decoder_shapes(c), 3)
+    m = AutoencoderKL(c)
+    m.load_state_dict(wd)
+    m = m.to(DEV, torch.float32)
+    lat = synth.normal_like(21, (1, 4, 8, 8), 1.0)
+    ref = S.vae_decode(wd, c, lat)
+    y = m.decode((lat / c["scaling_factor"]).to(DEV)).sample
+    assert rel(y, ref) < 2e-4
+
+
+def test_pipeline_euler_cfg_tiny():
+    """Whole denoising loop (4 Euler steps, CFG 7.5) + VAE decode + uint8 post-processing, fp32."""
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, StableDiffusionXLPipeline
+    m, wd, c = _unet(torch.float32)
+    vc = S.TINY_VAE
+    vwd = S.synth_weights(S.vae_decoder_shapes(vc), 2)
+    vae = AutoencoderKL(vc)
+    vae.load_state_dict(vwd)
+    vae = vae.to(DEV, torch.float32)
+    pipe = StableDiffusionXLPipeline(vae=vae, unet=m, scheduler=EulerDiscreteScheduler())
+    cp, cn = synth.normal_like(30, (1, 8, 128), 1.0), synth.normal_like(31, (1, 8, 128), 1.0)
+    pp, pn = synth.normal_like(32, (1, 80), 1.0), synth.normal_like(33, (1, 80), 1.0)
+    noise = synth.normal_like(34, (1, 4, 8, 8), 1.0)
+    ref_lat = S.sdxl_generate_latents(wd, c, cp, cn, pp, pn, noise, steps=4, guidance=7.5, size=64)
+    out = pipe(prompt_embeds=cp.to(DEV), negative_prompt_embeds=cn.to(DEV), pooled_prompt_embeds=pp.to(DEV),
+               negative_pooled_prompt_embeds=pn.to(DEV), guidance_scale=7.5, num_inference_steps=4, height=64, width=64,
+               latents=noise.to(DEV), output_type="latent").images
+    assert rel(out, ref_lat) < 5e-4
+    img = pipe(prompt_embeds=cp.to(DEV), negative_prompt_embeds=cn.to(DEV), pooled_prompt_embeds=pp.to(DEV),
+               negative_pooled_prompt_embeds=pn.to(DEV), guidance_scale=7.5, num_inference_steps=4, height=64, width=64,
+               latents=noise.to(DEV), output_type="pt").images
+    ref_img = S.postprocess(S.vae_decode(vwd, vc, ref_lat))[0]
+    assert img.shape == ref_img.shape == (64, 64, 3)
+    assert (img.cpu().float() - ref_img.float()).abs().mean() < 1.0       # uint8 levels
+
+
+def test_resampler_xlv2(golden):
+    from src.models_ipa.resampler import ResamplerXLV2
+    g, meta = golden
+    c = meta["XLV2"]
+    wd = synth.resampler_xlv2_weights(41, **c)
+    m = ResamplerXLV2(**c)
+    missing, unexpected = m.load_state_dict(wd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    m = m.to(DEV)
+    ctx, pooled = m(g["xlv2.x"].to(DEV))
+    assert rel(ctx, g["xlv2.ctx"]) < 1e-4
+    assert rel(pooled, g["xlv2.pooled"]) < 1e-4
+
+
+def test_sdxl_adapter_generate_tiny():
+    """SDXLAdapter.generate through the reference API surface (init_pipe / generate -> PIL images)."""
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler
+    from src.models.discrete_models import DiscreteModleIdentity
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    from src.models_ipa.adapter_modules import SDXLAdapter
+    from src.models_ipa.resampler import ResamplerXLV2
+    m, wd, c = _unet(torch.float32)
+    rs = ResamplerXLV2(dim=128, depth=2, dim_head=32, heads=4, num_queries=8, embedding_dim=256, output1_dim=48,
+                       output2_dim=80, ff_mult=4).init_synthetic(5)
+    vit = VisionTransformerWithAttnPool(image_size=56, patch_size=14, width=208, layers=1, heads=2, mlp_ratio=2.0,
+                                        n_queries=16, output_dim=256).init_synthetic(6)
+    vae = AutoencoderKL(S.TINY_VAE).init_synthetic(7)
+    adapter = SDXLAdapter.from_pretrained(unet=m, resampler=rs).to(DEV).eval()
+    adapter.init_pipe(vae=vae.to(DEV), scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+                      discrete_model=DiscreteModleIdentity(), dtype=torch.float32, device=DEV)
+    feat = synth.normal_like(50, (1, 16, 256), 1.0).to(DEV)
+    imgs = adapter.generate(image_embeds=feat, num_inference_steps=3, height=64, width=64, input_image_size=56)
+    assert len(imgs) == 1 and imgs[0].size == (64, 64)
+    imgs2 = adapter.generate(image_embeds=feat, num_inference_steps=3, height=64, width=64, input_image_size=56)
+    import numpy as np
+    a, b = np.asarray(imgs[0]).astype(np.int32), np.asarray(imgs2[0]).astype(np.int32)
+    # seed 42 -> same image; GroupNorm statistics use fp32 atomics (sum order varies): <= 1 uint8 level on a few pixels
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01
