@@ -5,15 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]; SURVEY.md §8d synthetic schedule): LLaMA-2-7B-shaped MLLM
-(random N(0,0.02) weights, bf16) + Qwen ViT-G encode + learnable-query image-feature regression,
-stories of 3 image-text pairs, no SDXL.  One *step* = one ``agent.generate`` of the reference
+Workload (default = BASELINE.json configs[2], the single-GPU configuration the metric
+"story-steps/sec (text + 1024x1024 image)" is quoted on; SURVEY.md §8d synthetic schedule):
+LLaMA-2-7B-shaped MLLM (random N(0,0.02) weights, bf16) + Qwen ViT-G encode + learnable-query
+image-feature regression + SDXL de-tokenizer (ResamplerXLV2 -> 30-step Euler, CFG 7.5, 1024x1024,
+random-init SDXL-base UNet/VAE, bf16), stories of 5 steps.  ``--mllm-only`` runs configs[1] (3 pairs,
+no SDXL).  One *step* = one ``agent.generate`` of the reference
 (gen_george.py:189/257): embed + splice the window's image features (input resampler over every
 image in context) -> prefill of the whole prompt (S = 115 / 229 / 343; "as released", no KV reuse;
 ``--kv-reuse`` switches to the 65-row continuation) -> 115 greedy decode iterations under the forced
 token schedule (48 caption ids, ``<img>``, 64 image tokens + ``</img>`` forced by the reference's
 logits processor, EOS) -> output resampler regression of the 64 hidden states to the 256x4096 image
-feature.  The first step of every story also encodes the 448x448 input image with ViT-G.
+feature -> ``adapter.generate`` (gen_george.py:210): ResamplerXLV2 conditioning + 30 x {UNet (batch 2,
+CFG) + Euler update} + VAE decode to a uint8 1024x1024 image.  The first step of every story also
+encodes the 448x448 input image with ViT-G (and the constant all-zeros negative image once).
 
 N > 1: one process per GPU, independent stories per rank (SURVEY §8e story-level replicas, no
 data-path collective), weak scaling; value = steps of all ranks / max-over-ranks time.
@@ -36,8 +41,23 @@ H, NH, NL, INTER, VOCAB = 4096, 32, 32, 11008, 32066
 IMG_IDS = list(range(32000, 32066))     # <img>, <img_00000..63>, </img>  (66 added tokens)
 BOS, EOS = 1, 2
 CAPTION = 48
-STORY_LEN = 3
+STORY_LEN = 5
 T_GEN = CAPTION + 66 + 1                 # caption + image tokens + EOS = 115 decode iterations
+
+
+def build_detokenizer(device, dtype, vit):
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, UNet2DConditionModel
+    from src.models.discrete_models import DiscreteModleIdentity
+    from src.models_ipa.adapter_modules import SDXLAdapter
+    from src.models_ipa.resampler import ResamplerXLV2
+    unet = UNet2DConditionModel().to(device=device, dtype=dtype).init_synthetic(4)
+    vae = AutoencoderKL().to(device=device, dtype=dtype).init_synthetic(5)
+    rs = ResamplerXLV2(dim=1024, depth=4, dim_head=64, heads=16, num_queries=64, embedding_dim=4096, output1_dim=768,
+                       output2_dim=1280, ff_mult=4).to(device=device, dtype=dtype).init_synthetic(6)
+    adapter = SDXLAdapter.from_pretrained(unet=unet, resampler=rs).eval()
+    adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+                      discrete_model=DiscreteModleIdentity(), dtype=dtype, device=device)
+    return adapter
 
 
 def build_models(device, dtype):
@@ -52,7 +72,7 @@ def build_models(device, dtype):
     layers = [(rnd(3 * H, H), rnd(H, H), rnd(2 * INTER, H), rnd(H, INTER), ones(H), ones(H)) for _ in range(NL)]
     eng = LlamaEngine.from_prebuilt(embed=rnd(VOCAB, H), lm_head=rnd(VOCAB, H), final_norm=ones(H), layers=layers,
                                     hidden=H, n_heads=NH, n_layers=NL, inter=INTER, vocab=VOCAB, dtype=dtype,
-                                    device=device, cache_cap=1024, max_new=128, max_prefill_rows=512, img_ids=IMG_IDS,
+                                    device=device, cache_cap=1024, max_new=128, max_prefill_rows=640, img_ids=IMG_IDS,
                                     eos_id=EOS)
     rin = Resampler(grid_size=8, embed_dim=H, num_heads=32, kv_dim=H).to(device=device, dtype=dtype).init_synthetic(1)
     rout = Resampler(grid_size=16, embed_dim=H, num_heads=32, kv_dim=H).to(device=device, dtype=dtype).init_synthetic(2)
@@ -83,7 +103,7 @@ class Story:
         return cap + IMG_IDS + [EOS]
 
 
-def run_step(st, eng, rin, rout, vit, kv_reuse):
+def run_step(st, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
     from seedstory import ops
     dev = st.device
     if st.step == 0:
@@ -108,13 +128,15 @@ def run_step(st, eng, rin, rout, vit, kv_reuse):
     e = CAPTION + 65                                                      # index of </img> in the generated ids
     feats = eng.hidden_rows[e - 64:e].unsqueeze(0).contiguous()           # models.py:197
     img_gen_feat = rout(feats)                                            # models.py:205  [1,256,4096]
+    if adapter is not None:                                               # gen_george.py:210 (30 steps: BASELINE)
+        st.last_image = adapter.generate(image_embeds=img_gen_feat, num_inference_steps=steps, output_type="pt")
     st.image_embeds = torch.cat([st.image_embeds, img_gen_feat], dim=0)   # gen_george.py:224
     st.ids = st.ids + forced[:CAPTION] + IMG_IDS                          # prompt + text + image_tokens (:231)
     st.step += 1
     return img_gen_feat
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=25.0, with_sdxl=True, diffusion_steps=30):
     """The oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a
     BOUNDED sample: a 2-layer full-width (4096/11008/32 heads) bf16 slice — one S=115 prefill and 4
     decode tokens — extrapolated to 32 layers + lm_head and to the 3-step story schedule."""
@@ -154,20 +176,47 @@ def cpu_baseline(seconds_budget=25.0):
     tok_full = layer_tok * (NL + 0.65)
     prefill_full_115 = t_prefill / (L + 0.65 / S) * NL
     # 3-step story: prefill S = 115, 229, 343 (linear in S at these sizes) + 115 tokens each
-    step_s = (prefill_full_115 * (115 + 229 + 343) / 115.0 / 3.0) + T_GEN * tok_full
+    lens = [115 + 114 * i for i in range(STORY_LEN)]
+    step_s = (prefill_full_115 * sum(lens) / 115.0 / len(lens)) + T_GEN * tok_full
+    sample = ("oracle llama_forward, bf16, 2 full-width layers: one S=115 prefill (%.2fs) + %d decode tokens "
+              "(%.3fs/token), extrapolated to 32 layers+lm_head and the %d-step story" % (t_prefill, ntok, t_tok, STORY_LEN))
+    if with_sdxl:
+        import sdxl_oracle as S
+        c = S.SDXL_BASE_UNET
+        t0 = time.perf_counter()
+        wdu = {k: torch.empty(*shp).normal_(0.0, 0.02) if len(shp) > 1 else torch.ones(*shp)
+               for k, shp in S.unet_shapes(c).items()}
+        t_w = time.perf_counter() - t0
+        x = torch.randn(1, 4, 64, 64)
+        ctx = torch.randn(1, 64, 2048)
+        pooled = torch.randn(1, 1280)
+        tid = torch.tensor([[512, 512, 0, 0, 512, 512]], dtype=torch.float32)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            S.unet_forward(wdu, c, x, torch.tensor(500.0), ctx, pooled, tid)
+        t_unet = time.perf_counter() - t0
+        del wdu
+        # 1024^2 = 4x the pixels of the sample (conv/FF scale 4x; self-attention 16x, ~11 % of the MACs): x4.4;
+        # x2 CFG branches x diffusion steps; VAE decode (10.5 TFLOP fp32) priced at the UNet sample's flop rate
+        unet_full = t_unet * 4.4
+        flop_rate = 1.69e12 / t_unet
+        render_s = diffusion_steps * 2 * unet_full + 10.5e12 / flop_rate
+        step_s += render_s
+        sample += ("; + oracle SDXL-base UNet forward fp32, batch 1 at 64x64 latents (%.1fs; weights %.0fs), extrapolated "
+                   "to 128x128 latents x2 (CFG) x%d Euler steps + VAE decode at the same flop rate" % (t_unet, t_w, diffusion_steps))
     return {"value": round(1.0 / step_s, 6), "unit": "story-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle llama_forward, bf16, 2 full-width layers: one S=115 prefill (%.2fs) + %d decode tokens "
-                      "(%.3fs/token); extrapolated to 32 layers+lm_head and the 3-step story (ViT/resamplers "
-                      "excluded, <2%% of the step)" % (t_prefill, ntok, t_tok)}
+            "sample": sample + " (ViT/resamplers excluded, <2% of the step)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kv-reuse", action="store_true", help="65-row KV-cached continuation instead of re-prefill")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mllm-only", action="store_true", help="BASELINE configs[1]: no SDXL render, 3-pair stories")
+    ap.add_argument("--diffusion-steps", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +232,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = torch.bfloat16
+    global STORY_LEN
+    if args.mllm_only:
+        STORY_LEN = 3
     eng, rin, rout, vit = build_models(device, dtype)
+    adapter = None if args.mllm_only else build_detokenizer(device, dtype, vit)
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,7 +251,7 @@ def main():
         if st[0] is None or st[0].step >= STORY_LEN:
             story_no[0] += 1
             st[0] = Story(story_no[0], device)
-        return run_step(st[0], eng, rin, rout, vit, args.kv_reuse)
+        return run_step(st[0], eng, rin, rout, vit, args.kv_reuse, adapter, args.diffusion_steps)
 
     for _ in range(args.warmup):
         one_step()
@@ -241,18 +294,48 @@ def main():
                                                           ((prof["gemv_ms"] + prof["gemv_down_ms"]) * 1e-3) / 1e9, 1),
                          "token_ms_eager": round(prof["token_ms"], 4), "attn_ms": round(prof["attn_ms"], 4),
                          "misc_ms": round(prof["misc_ms"], 4)}}
+    if rank == 0 and adapter is not None:
+        # MFMA-bound half: one SDXL-base UNet forward (batch 2 = CFG pair, 128x128 latents), HIP events on the stream
+        x = torch.randn(2, 4, 128, 128, device=device, dtype=dtype)
+        ctx = torch.randn(2, 64, 2048, device=device, dtype=dtype)
+        cond = {"text_embeds": torch.randn(2, 1280, device=device, dtype=dtype),
+                "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)}
+        adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        flops = 2 * 6.747e12                                   # 3.3735 TMAC per sample per forward
+        roof_mllm = roof
+        roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": None,
+                "kernel": "SDXL UNet forward (ss::gemm_kernel<bf16,*> incl. implicit-GEMM conv3x3 + ss::flash_attn_kernel<bf16,64>)",
+                "flops_per_forward": flops, "forward_ms": round(ms, 3),
+                "note": "the step is 60 UNet forwards (MFMA-bound) + 115 decode tokens (HBM-bound): see mllm_decode_gemv",
+                "mllm_decode_gemv": roof_mllm}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(with_sdxl=not args.mllm_only, diffusion_steps=args.diffusion_steps)
     if rank == 0:
         total_steps = args.steps * world
-        out = {"metric": "story-steps/sec (text + image-feature regression; 3-pair StoryStream-shaped sequence, MLLM half)",
+        if args.mllm_only:
+            workload = ("BASELINE configs[1]: LLaMA-7B MLLM (prefill S=115/229/343 + 115 greedy decode iterations) + Qwen "
+                        "ViT-G encode per story + input/output Resampler regression, bf16, 3 image-text pairs, no SDXL")
+            metric = "story-steps/sec (text + image-feature regression, MLLM half only)"
+        else:
+            workload = ("BASELINE configs[2]: full pipeline on 1 GPU per replica — LLaMA-7B MLLM (prefill S=115..571 + 115 "
+                        "greedy decode iterations) + Qwen ViT-G encode + Resampler regression + SDXL de-tokenizer "
+                        "(ResamplerXLV2, %d Euler steps x CFG batch 2 UNet, VAE decode) -> 1024x1024 uint8 image, bf16, "
+                        "story length 5" % args.diffusion_steps)
+            metric = "story-steps/sec (text + 1024x1024 image)"
+        out = {"metric": metric,
                "value": round(total_steps / dt_s, 4), "unit": "story-steps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: LLaMA-7B MLLM (prefill S=115/229/343 + 115 greedy decode "
-                                      "iterations) + Qwen ViT-G encode per story + input/output Resampler regression, "
-                                      "bf16, 3 image-text pairs per story, no SDXL",
+               "config": {"workload": workload, "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
                           "parallelism": "story replicas x%d" % world},
                "roofline": roof, "cpu_baseline": cpu}

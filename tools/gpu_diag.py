@@ -175,12 +175,51 @@ def bench_decode():
     OUT["decode"] = res
 
 
+def bench_sdxl():
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, StableDiffusionXLPipeline, UNet2DConditionModel
+    res = {}
+    dt = torch.bfloat16
+    unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
+    vae = AutoencoderKL().to(DEV, dt).init_synthetic(2)
+    x = torch.randn(2, 4, 128, 128, device=DEV, dtype=dt)
+    ctx = torch.randn(2, 64, 2048, device=DEV, dtype=dt)
+    pooled = torch.randn(2, 1280, device=DEV, dtype=dt)
+    tid = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)
+    cond = {"text_embeds": pooled, "time_ids": tid}
+    for _ in range(2):
+        unet(x, 500.0, ctx, added_cond_kwargs=cond)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        y = unet(x, 500.0, ctx, added_cond_kwargs=cond).sample
+    torch.cuda.synchronize()
+    res["unet_fwd_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    res["unet_TFLOPs"] = round(2 * 6.747e12 / (res["unet_fwd_ms"] * 1e-3) / 1e12, 1)
+    res["unet_out_finite"] = bool(torch.isfinite(y.float()).all())
+    print(res, flush=True)
+    lat = torch.randn(1, 4, 128, 128, device=DEV, dtype=dt)
+    vae.decode_nhwc(lat)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    img, H, W = vae.decode_nhwc(lat)
+    torch.cuda.synchronize()
+    res["vae_decode_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    print(res, flush=True)
+    pipe = StableDiffusionXLPipeline(vae=vae, unet=unet, scheduler=EulerDiscreteScheduler())
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = pipe(prompt_embeds=ctx[:1], negative_prompt_embeds=ctx[1:], pooled_prompt_embeds=pooled[:1],
+               negative_pooled_prompt_embeds=pooled[1:], num_inference_steps=30, height=1024, width=1024, output_type="pt").images
+    torch.cuda.synchronize()
+    res["pipeline_30_steps_s"] = round(time.perf_counter() - t0, 3)
+    res["image_shape"] = list(out.shape)
+    print(res, flush=True)
+    OUT["sdxl"] = res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn", "decode"]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for w in which:
         try:
-            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode}[w]()
+            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode, "sdxl": bench_sdxl}[w]()
         except Exception as ex:  # keep going: one broken kernel must not hide the other numbers
             import traceback
             traceback.print_exc()
