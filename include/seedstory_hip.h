@@ -292,11 +292,12 @@ int ss_vit_forward(const ss_vit_weights* w, const void* img, void* out, int64_t 
  * ResnetBlock2D.conv1/conv2, Downsample2D.conv, Upsample2D.conv, conv_in/conv_out):
  * x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; w [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci (re-laid once at
  * load); upsample2x fuses F.interpolate(scale 2, nearest) of the input into the gather;
- * bias [Cout] | NULL; rowvec [B, Cout] | NULL is added after the bias (ResBlock time embedding,
- * `h + temb[:, :, None, None]`); residual [B,Ho,Wo,Cout] | NULL is added last. Cin % 8 == 0. */
+ * bias [Cout] | NULL; rowvec | NULL = per-batch vector added after the bias (ResBlock time embedding,
+ * `h + temb[:, :, None, None]`): element (b, co) at rowvec[b * rowvec_stride + co] (stride 0 = Cout);
+ * residual [B,Ho,Wo,Cout] | NULL is added last. Cin % 8 == 0. */
 int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, int64_t W, int64_t Cin,
                int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
-               const void* residual, int dtype, void* stream);
+               int64_t rowvec_stride, const void* residual, int dtype, void* stream);
 
 /* nn.GroupNorm over NHWC (+ optional fused SiLU): fp32 statistics per (batch, group);
  * stats_ws = batch*groups*2 floats of scratch. */

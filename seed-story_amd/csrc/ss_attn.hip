@@ -215,6 +215,228 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// (1b) flash attention v2 (bf16 / f16): same S^T = K Q^T / O^T = V^T P^T lane algebra, but
+//   * 32 query rows per wave (128 per block): every K / V fragment read from LDS feeds two MFMAs;
+//   * K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4, inline asm so hipcc does not drain it),
+//     double-buffered, one barrier per 64-key tile;
+//   * K image XOR-swizzled (conflict-free ds_read_b128, as in the GEMM); V image row-major and read with
+//     ds_read_b64_tr_b16: inside a 16-lane group lane i points at key i/4, d (i%4)*4 and receives
+//     [4 keys][d = i] (probed on MI355X, tools/tr_probe.py) = exactly the V^T fragment — no transposed
+//     scalar LDS writes;
+//   * exp2 with the scale folded in (log2 domain running max).
+// --------------------------------------------------------------------------------------------
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+typedef __attribute__((address_space(3))) void lds_void2_t;
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[64];
+
+__device__ __forceinline__ void attn_dma16(const void* gsrc, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void flash_attn2_kernel(const AttnArgs a) {
+    constexpr int V = 8;
+    constexpr int BQ2 = 128;             // query rows per block: 4 waves x 32
+    constexpr int CPR = HD / V;          // 16-byte chunks per key row
+    constexpr int KPI = 64 / CPR;        // keys per DMA instruction
+    constexpr int NI = kBKV / KPI;       // DMA instructions per tile per operand
+    constexpr int IPW = NI / 4;          // ... per wave
+    constexpr int ROWB = HD * 2;         // bytes per key row
+    constexpr int TILE_B = kBKV * ROWB;  // bytes of one K (or V) tile
+    constexpr int NDB = HD / 16, NKB = kBKV / 16, NKS = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // [buf][K tile | V tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.n_heads, h = bh % a.n_heads;
+    const int q0 = blockIdx.x * BQ2;
+    const int hd = a.hd;
+    const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+    const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int shift = a.kv_len - a.q_len;
+    const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void2_t*)smem_raw);
+    const float sl2 = a.scale * 1.4426950408889634f;   // scores kept in the log2 domain
+
+    int qi[2];
+    uint4 qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = q0 + wid * 32 + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + grp * 8;
+            qf[qb][ks] = (qi[qb] < a.q_len && d < hd) ? ld16(qp + (int64_t)qi[qb] * a.q_ss + d) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    f32x4_t o[2][NDB];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) o[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+    int kv_end = a.kv_len;
+    if (a.causal_br) {
+        const int lim = q0 + BQ2 - 1 + shift + 1;
+        if (lim < kv_end) kv_end = lim;
+        if (kv_end < 0) kv_end = 0;
+    }
+    const int ntiles = (kv_end + kBKV - 1) / kBKV;
+
+    // DMA coordinates of this lane: key row within the instruction and physical chunk
+    const int skey = lane / CPR, spc = lane % CPR;
+    auto issue_tile = [&](int t, int buf) {
+        const uint32_t kbase = lds0 + (uint32_t)(buf * 2 * TILE_B);
+        const uint32_t vbase = kbase + TILE_B;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int key = (wid * IPW + i) * KPI + skey;       // key row inside the tile
+            const int kg = t * kBKV + key;
+            const int lc = spc ^ (key & (CPR - 1));               // K: swizzled on the source side
+            const bool okk = kg < a.kv_len && lc * V < hd;
+            const bool okv = kg < a.kv_len && spc * V < hd;
+            const T* ks = okk ? kp + (int64_t)kg * a.k_ss + lc * V : zero;
+            const T* vs = okv ? vp + (int64_t)kg * a.v_ss + spc * V : zero;
+            const uint32_t roff = (uint32_t)((wid * IPW + i) * KPI * ROWB);
+            attn_dma16(ks, __builtin_amdgcn_readfirstlane(kbase + roff));
+            attn_dma16(vs, __builtin_amdgcn_readfirstlane(vbase + roff));
+        }
+    };
+
+    if (ntiles > 0) issue_tile(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+        const char* Kb = smem_raw + (t & 1) * 2 * TILE_B;
+        const char* Vb = Kb + TILE_B;
+        const int t0 = t * kBKV;
+
+        // ---- S^T = K Q^T for both 16-row query blocks ---------------------------------------------
+        f32x4_t s[2][NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            s[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            s[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int r = kb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Kb + r * ROWB + (((ks * 4 + grp) ^ (r & (CPR - 1))) << 4));
+                s[0][kb] = AttnMma<T>::run(kf, qf[0][ks], s[0][kb]);
+                s[1][kb] = AttnMma<T>::run(kf, qf[1][ks], s[1][kb]);
+            }
+        }
+        // ---- online softmax (log2 domain) --------------------------------------------------------------
+        uint4 pfrag[2][NKB / 2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = -1e30f;
+            bool msk[NKB][4];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kg = t0 + kb * 16 + grp * 4 + r;
+                    const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
+                    msk[kb][r] = ok;
+                    const float sv = ok ? s[qb][kb][r] * sl2 : -1e30f;
+                    s[qb][kb][r] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qb], tmax);
+            const float alpha = exp2f(m_run[qb] - m_new);
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = msk[kb][r] ? exp2f(s[qb][kb][r] - m_new) : 0.f;
+                    s[qb][kb][r] = p;
+                    lsum += p;
+                }
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            l_run[qb] = l_run[qb] * alpha + lsum;
+            m_run[qb] = m_new;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][i][r] *= alpha;
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+                float pf[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pf[r] = s[qb][2 * kp2][r]; pf[4 + r] = s[qb][2 * kp2 + 1][r]; }
+                pfrag[qb][kp2] = pack<T>(pf);
+            }
+        }
+        // ---- O^T += V^T P^T: V^T fragments by transposed LDS reads, shared by both query blocks --------
+#pragma unroll
+        for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int kr0 = (2 * kp2) * 16 + grp * 4 + (l15 >> 2);
+                const int dcol = db * 16 + (l15 & 3) * 4;
+                const v4s_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(Vb + kr0 * ROWB + dcol * 2));
+                const v4s_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(Vb + (kr0 + 16) * ROWB + dcol * 2));
+                uint4 vfrag;
+                vfrag.x = (uint32_t)(uint16_t)v0[0] | ((uint32_t)(uint16_t)v0[1] << 16);
+                vfrag.y = (uint32_t)(uint16_t)v0[2] | ((uint32_t)(uint16_t)v0[3] << 16);
+                vfrag.z = (uint32_t)(uint16_t)v1[0] | ((uint32_t)(uint16_t)v1[1] << 16);
+                vfrag.w = (uint32_t)(uint16_t)v1[2] | ((uint32_t)(uint16_t)v1[3] << 16);
+                o[0][db] = AttnMma<T>::run(vfrag, pfrag[0][kp2], o[0][db]);
+                o[1][db] = AttnMma<T>::run(vfrag, pfrag[1][kp2], o[1][db]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qi[qb] >= a.q_len) continue;
+        const float inv = l_run[qb] > 0.f ? 1.0f / l_run[qb] : 0.f;
+        T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi[qb] * a.o_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int d = db * 16 + grp * 4;
+            if (d + 3 < hd && ((a.o_ss | a.o_sh | a.o_sb) & 3) == 0) {
+                float pk[8] = {o[qb][db][0] * inv, o[qb][db][1] * inv, o[qb][db][2] * inv, o[qb][db][3] * inv, 0, 0, 0, 0};
+                const uint4 u = pack<T>(pk);
+                *reinterpret_cast<uint2*>(op + d) = make_uint2(u.x, u.y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (d + r < hd) Tr<T>::st(op + d + r, o[qb][db][r] * inv);
+            }
+        }
+    }
+}
+
+template <typename T, int HD>
+static int flash2_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * kBKV * HD * 2;
+    dim3 grid((unsigned)cdiv(a.q_len, 128), (unsigned)(batch * a.n_heads));
+    hipLaunchKernelGGL((flash_attn2_kernel<T, HD>), grid, dim3(256), lds, s, a);
+    SS_LAUNCH_CHECK("flash_attn2");
+    return SS_OK;
+}
+
 template <typename T, int HD>
 static int flash_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
@@ -235,6 +457,13 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     SS_REQUIRE(!a.causal_br || a.kv_len >= a.q_len, "attention: causal needs kv_len >= q_len");
     if (a.q_len == 0 || batch == 0) return SS_OK;
     SS_REQUIRE(a.kv_len > 0, "attention: kv_len == 0");
+    if constexpr (V == 8) {
+        // v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill its 128-row blocks
+        if (tuning_get("attn_v2", 1) && a.q_len >= 32) {
+            if (a.hd <= 64) return flash2_launch_hd<T, 64>(a, batch, s);
+            return flash2_launch_hd<T, 128>(a, batch, s);
+        }
+    }
     if (a.hd <= 64) return flash_launch_hd<T, 64>(a, batch, s);
     return flash_launch_hd<T, 128>(a, batch, s);
 }

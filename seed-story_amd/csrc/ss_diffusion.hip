@@ -387,3 +387,23 @@ int ss_image_to_u8(const void* in, void* out_u8, int64_t pixels, int64_t cpad, i
 }
 
 }  // extern "C"
+
+// ---- debug probe: semantics of ds_read_b64_tr_b16 (used when developing the attention kernel) -----------
+namespace ss {
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+__global__ void tr_probe_kernel(const uint16_t* src, uint16_t* dst, const int* lane_off) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) sm[i] = src[i];
+    __syncthreads();
+    const int off = lane_off[threadIdx.x];
+    v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(sm + off));
+    for (int j = 0; j < 4; ++j) dst[threadIdx.x * 4 + j] = (uint16_t)r[j];
+}
+}  // namespace ss
+extern "C" int ss_debug_tr_probe(const void* src, void* dst, const void* lane_off, void* stream) {
+    hipLaunchKernelGGL(ss::tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)src,
+                       (uint16_t*)dst, (const int*)lane_off);
+    SS_LAUNCH_CHECK("tr_probe");
+    return SS_OK;
+}

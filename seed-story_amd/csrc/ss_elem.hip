@@ -118,12 +118,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Narrow rows (<= 256 packs, e.g. the UNet's 640/1280-wide tokens): one WAVE per row, 4 rows per block —
+// shuffle reductions only, no LDS, no barriers, every lane busy.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                             const T* __restrict__ b, T* __restrict__ y, int64_t rows,
+                                                             int cols, float eps) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int MAXP = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int npack = cols / V;
+    const T* xr = x + row * (int64_t)cols;
+    T* yr = y + row * (int64_t)cols;
+    uint4 px[MAXP];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = lane + i * 64;
+        if (p < npack) {
+            px[i] = ld16(xr + (int64_t)p * V);
+            float f[V];
+            unpack<T>(px[i], f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s1 += f[j];
+        }
+    }
+    const float mean = wave_sum(s1) / (float)cols;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = lane + i * 64;
+        if (p < npack) {
+            float f[V];
+            unpack<T>(px[i], f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = f[j] - mean; s2 = fmaf(d, d, s2); }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = lane + i * 64;
+        if (p < npack) {
+            float f[V], g[V], h[V];
+            unpack<T>(px[i], f);
+            unpack<T>(ld16(w + (int64_t)p * V), g);
+            unpack<T>(ld16(b + (int64_t)p * V), h);
+#pragma unroll
+            for (int j = 0; j < V; ++j) f[j] = (f[j] - mean) * rstd * g[j] + h[j];
+            st16(yr + (int64_t)p * V, pack<T>(f));
+        }
+    }
+}
+
 template <typename T>
 int layernorm_launch(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t cols, float eps,
                      hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(cols % V == 0 && cols / V <= kNormMaxPacks * 256, "layernorm: cols=%lld unsupported", (long long)cols);
     if (rows == 0) return SS_OK;
+    if (cols / V <= 256 && rows >= 256) {
+        hipLaunchKernelGGL(layernorm_wave_kernel<T>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, (const T*)x,
+                           (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);
+        SS_LAUNCH_CHECK("layernorm_wave");
+        return SS_OK;
+    }
     hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)rows), dim3(256), 0, s, (const T*)x, (const T*)w,
                        (const T*)b, (T*)y, (int)cols, eps);
     SS_LAUNCH_CHECK("layernorm");

@@ -44,7 +44,7 @@ struct GemmArgs {
     int64_t lda, ldw, ldc, ldr;
     int epi;
     // per-(batch, n) additive vector (the ResBlock's projected time embedding): rowvec[m / rows_per_batch][n]
-    const void* rowvec; int rows_per_batch;
+    const void* rowvec; int rows_per_batch; int64_t rowvec_ld;
     // implicit-GEMM 3x3 convolution over an NHWC tensor (A = [B, H, W, Cin]); K = 9 * Cin
     int conv_H, conv_W, conv_Cin, conv_stride, conv_up, conv_Ho, conv_Wo;
 };
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             float v[4];
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (g.rowvec) {
-                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * N;
+                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
             }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             float v[4];
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (g.rowvec) {
-                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * N;
+                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
             }
@@ -471,7 +471,7 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.residual = residual;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
-    g.rowvec = nullptr; g.rows_per_batch = 1;
+    g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
     return gemm_dispatch_cfg<T>(pick_cfg(M, N), g, s);
 }
@@ -480,8 +480,8 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
 // x [B, H, W, Cin] -> y [B, Ho, Wo, Cout];  w [Cout, 9*Cin] with k = (ky*3 + kx)*Cin + ci.
 template <typename T>
 int conv3x3_launch(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t Wd, int64_t Cin, int64_t Cout,
-                   int64_t stride, int64_t up, const void* bias, const void* rowvec, const void* residual, int epi,
-                   hipStream_t s) {
+                   int64_t stride, int64_t up, const void* bias, const void* rowvec, int64_t rowvec_ld,
+                   const void* residual, int epi, hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(Cin % V == 0, "conv3x3: Cin=%lld must be a multiple of %d (pad the channels)", (long long)Cin, V);
     SS_REQUIRE((stride == 1 || stride == 2) && !(up && stride != 1), "conv3x3: unsupported stride/upsample");
@@ -491,7 +491,7 @@ int conv3x3_launch(const void* x, const void* w, void* y, int64_t B, int64_t H, 
     g.A = x; g.W = w; g.C = y; g.bias = bias; g.residual = residual;
     g.M = (int)(B * Ho * Wo); g.N = (int)Cout; g.K = (int)(9 * Cin);
     g.lda = 0; g.ldw = 9 * Cin; g.ldc = Cout; g.ldr = Cout; g.epi = epi;
-    g.rowvec = rowvec; g.rows_per_batch = (int)(Ho * Wo);
+    g.rowvec = rowvec; g.rows_per_batch = (int)(Ho * Wo); g.rowvec_ld = rowvec_ld > 0 ? rowvec_ld : Cout;
     g.conv_H = (int)H; g.conv_W = (int)Wd; g.conv_Cin = (int)Cin; g.conv_stride = (int)stride; g.conv_up = (int)up;
     g.conv_Ho = (int)Ho; g.conv_Wo = (int)Wo;
     if (g.M == 0) return SS_OK;
@@ -507,10 +507,10 @@ int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_
 
 extern "C" int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, int64_t W_, int64_t Cin,
                           int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
-                          const void* residual, int dtype, void* stream) {
+                          int64_t rowvec_stride, const void* residual, int dtype, void* stream) {
     const int epi = (bias ? SS_EPI_BIAS : 0) | (residual ? SS_EPI_RESIDUAL : 0);
     return SS_DISPATCH(dtype, ss::conv3x3_launch, x, w, y, batch, H, W_, Cin, Cout, stride, upsample2x, bias, rowvec,
-                       residual, epi, (hipStream_t)stream);
+                       rowvec_stride, residual, epi, (hipStream_t)stream);
 }
 
 extern "C" int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,

@@ -89,7 +89,7 @@ PROTOTYPES = {
     "ss_resampler_forward": (C.c_int, [C.POINTER(ResamplerWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
     "ss_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i64, C.c_int]),
     "ss_vit_forward": (C.c_int, [C.POINTER(VitWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
-    "ss_conv3x3": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, vp, C.c_int, vp]),
+    "ss_conv3x3": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, C.c_int, vp]),
     "ss_groupnorm": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, C.c_int, C.c_int, vp]),
     "ss_geglu": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),
     "ss_unary": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),

@@ -278,16 +278,29 @@ class UNet2DConditionModel(nn.Module):
             if k.endswith("attn2.to_k.weight"):
                 b = k[:-len("to_k.weight")]
                 P[b + "kv"] = torch.cat([sd[b + "to_k.weight"], sd[b + "to_v.weight"]], 0).contiguous()
+        # every ResBlock's time_emb_proj stacked into one [sum(Cout), temb] matrix: one GEMM per forward
+        # instead of 17-23 latency-bound M=2 launches; each block reads its slice through rowvec_stride
+        names = [k[:-len(".time_emb_proj.weight")] for k in sd if k.endswith(".time_emb_proj.weight")]
+        if names:
+            P["temb_all.weight"] = torch.cat([sd[n + ".time_emb_proj.weight"] for n in names], 0).contiguous()
+            P["temb_all.bias"] = torch.cat([sd[n + ".time_emb_proj.bias"] for n in names], 0).contiguous()
+            off = 0
+            P["temb_all.offsets"] = {}
+            for n in names:
+                P["temb_all.offsets"][n] = off
+                off += sd[n + ".time_emb_proj.weight"].shape[0]
         self._prep, self._prep_sig = P, sig
         return P
 
     # -- forward ----------------------------------------------------------------------------------------------
     def _resnet(self, P, n, x, B, H, W, temb_act, groups, eps=1e-5):
         h = ops.groupnorm(x, P[n + ".norm1.weight"], P[n + ".norm1.bias"], B, groups, eps, silu=True)
-        tp = None
-        if temb_act is not None:
-            tp = ops.gemm(temb_act, P[n + ".time_emb_proj.weight"], bias=P[n + ".time_emb_proj.bias"])
-        h, _, _ = ops.conv3x3(h, P[n + ".conv1.weight"], B, H, W, bias=P[n + ".conv1.bias"], rowvec=tp)
+        tp, tld = None, 0
+        if temb_act is not None:                                        # temb_act = stacked projections [B, sum(Cout)]
+            off = P["temb_all.offsets"][n]
+            tld = temb_act.shape[1]
+            tp = temb_act[:, off:]                                      # view: row stride tld, first Cout columns used
+        h, _, _ = ops.conv3x3(h, P[n + ".conv1.weight"], B, H, W, bias=P[n + ".conv1.bias"], rowvec=tp, rowvec_stride=tld)
         h = ops.groupnorm(h, P[n + ".norm2.weight"], P[n + ".norm2.bias"], B, groups, eps, silu=True)
         sc = x
         if (n + ".conv_shortcut.weight") in P:
@@ -333,6 +346,7 @@ class UNet2DConditionModel(nn.Module):
         emb = ops.gemm(ops.silu(ops.gemm(add, P["add_embedding.linear_1.weight"], bias=P["add_embedding.linear_1.bias"])),
                        P["add_embedding.linear_2.weight"], bias=P["add_embedding.linear_2.bias"], residual=emb)
         temb_act = ops.silu(emb)                                            # F.silu(temb) feeds every ResBlock
+        temb_act = ops.gemm(temb_act, P["temb_all.weight"], bias=P["temb_all.bias"])   # all time_emb_proj at once
         ctx = encoder_hidden_states.to(dt).contiguous()
         Lctx = ctx.shape[1]
         ctx2d = ctx.view(B * Lctx, -1)

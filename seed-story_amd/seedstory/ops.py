@@ -189,7 +189,7 @@ def imgproc_argmax(logits, last_id, img_ids):
 
 
 # ---- SDXL de-tokenizer ops (NHWC activations: [B, H*W, C]) ------------------------------------------
-def conv3x3(x, w, B, H, W, stride=1, upsample=False, bias=None, rowvec=None, residual=None):
+def conv3x3(x, w, B, H, W, stride=1, upsample=False, bias=None, rowvec=None, residual=None, rowvec_stride=0):
     """x [B*H*W, Cin] (NHWC) -> [B*Ho*Wo, Cout]; w [Cout, 9*Cin] (tap-major, channel-minor)."""
     _req(x); _req(w)
     Cin = x.shape[-1]
@@ -197,8 +197,8 @@ def conv3x3(x, w, B, H, W, stride=1, upsample=False, bias=None, rowvec=None, res
     Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
     Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
     y = torch.empty(B * Ho * Wo, Cout, dtype=x.dtype, device=x.device)
-    check(lib().ss_conv3x3(p(x), p(w), p(y), B, H, W, Cin, Cout, stride, int(upsample), p(bias), p(rowvec), p(residual),
-                           dt(x), stream()), "ss_conv3x3")
+    check(lib().ss_conv3x3(p(x), p(w), p(y), B, H, W, Cin, Cout, stride, int(upsample), p(bias), p(rowvec),
+                           rowvec_stride, p(residual), dt(x), stream()), "ss_conv3x3")
     return y, Ho, Wo
 
 
