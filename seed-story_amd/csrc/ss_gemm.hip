@@ -16,6 +16,10 @@
 // Tiles: <BM, BN, WM, WN> = block tile (activation rows x weight rows) and the wave grid.
 // Global -> register -> LDS staging with the next tile's loads in flight during the MFMAs
 // (guide T14 write-late form), padded LDS rows (+1 pack) to break the 128-byte stride.
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "ss_common.h"
 
 namespace ss {
@@ -261,7 +265,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
         : "memory");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool CONV>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int V = 8;
     constexpr int NW = WM * WN;
@@ -311,7 +319,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
             const int m = m_blk + r8 + srow;
             const T* src = zero;
             if constexpr (CONV) {
-                const int tap = k / g.conv_Cin, ci = k - tap * g.conv_Cin;
+                // Cin % 64 == 0 (every UNet / VAE conv but conv_in): the whole 64-wide k-tile lies inside one
+                // filter tap, so the tap is a wave-uniform scalar division per tile instead of one per lane
+                int tap, ci;
+                if ((g.conv_Cin & 63) == 0) {
+                    const int k0 = t * BK;
+                    tap = k0 / g.conv_Cin;
+                    ci = k0 - tap * g.conv_Cin + schunk * V;
+                } else {
+                    tap = k / g.conv_Cin;
+                    ci = k - tap * g.conv_Cin;
+                }
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 int iy = cy[i] * g.conv_stride + dy, ix = cx[i] * g.conv_stride + dx;
                 const int Hin = g.conv_up ? 2 * g.conv_H : g.conv_H, Win = g.conv_up ? 2 * g.conv_W : g.conv_W;
@@ -338,12 +356,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    issue_tile(0, 0);
+    // NS-deep ring: tiles t+1 .. t+NS-2 stay in flight across the barrier (counted vmcnt, never drained
+    // in steady state); small tiles have too little MFMA work per tile to hide a DMA round trip otherwise.
+    constexpr int IPT = IA + IW;   // DMA instructions per tile per wave
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < ntiles) issue_tile(st, st);
+    int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile t have landed
-        __syncthreads();                                    // ... everyone's have; buf[(t+1)&1] is free again
-        if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
-        const char* abuf = smem_raw + (t & 1) * TILE_BYTES;
+        if (t + NS - 2 < ntiles) wait_vmcnt<(NS - 2) * IPT>();   // tile t landed; later tiles may still fly
+        else wait_vmcnt<0>();
+        __syncthreads();                                    // ... everyone's pieces too; buf[(t-1)%NS] is free again
+        if (t + NS - 1 < ntiles) {
+            int nb = buf + NS - 1;
+            if (nb >= NS) nb -= NS;
+            issue_tile(t + NS - 1, nb);
+        }
+        const char* abuf = smem_raw + buf * TILE_BYTES;
+        if (++buf == NS) buf = 0;
         const char* wbuf = abuf + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -413,15 +443,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NS = 2>
 static int gemm_glds_launch_cfg(const GemmArgs& g, hipStream_t s) {
     if constexpr (Tr<T>::kVec == 8) {
-        const size_t lds = (size_t)2 * (BM + BN) * 128;
+        const size_t lds = (size_t)NS * (BM + BN) * 128;
         dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
         if (g.conv_Cin > 0)
-            hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, g);
+            hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, true>), grid, dim3(64 * WM * WN), lds, s, g);
         else
-            hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, g);
+            hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NS, false>), grid, dim3(64 * WM * WN), lds, s, g);
         SS_LAUNCH_CHECK("gemm_glds");
         return SS_OK;
     } else {
@@ -442,6 +472,12 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
         case 9: return gemm_glds_launch_cfg<T, 256, 128, 4, 2>(g, s);
         case 10: return gemm_glds_launch_cfg<T, 64, 64, 2, 2>(g, s);
         case 11: return gemm_glds_launch_cfg<T, 128, 256, 2, 4>(g, s);
+        case 12: return gemm_glds_launch_cfg<T, 64, 64, 2, 2, 3>(g, s);
+        case 13: return gemm_glds_launch_cfg<T, 64, 64, 2, 2, 4>(g, s);
+        case 14: return gemm_glds_launch_cfg<T, 128, 64, 2, 2, 3>(g, s);
+        case 15: return gemm_glds_launch_cfg<T, 128, 64, 2, 2, 2>(g, s);
+        case 16: return gemm_glds_launch_cfg<T, 128, 128, 2, 2, 3>(g, s);
+        case 17: return gemm_glds_launch_cfg<T, 64, 128, 2, 2, 3>(g, s);
         default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
     }
 }
@@ -456,6 +492,57 @@ static int pick_cfg(int64_t M, int64_t N) {
     if (M <= 128) return 3;
     if (big_blocks >= 256) return 8;
     return 10;
+}
+
+
+// ---- per-shape autotuning of the tile configuration -------------------------------------------------
+// The best tile (128x128 / 128x64 / 64x64 DMA-staged kernels) depends on M, N, K in ways a closed-form rule
+// misses by 10-40 % (tools/gpu_diag.py gemm_unet).  The first call with a new (dtype, M, N, K, conv geometry)
+// times each candidate with HIP events on the caller's stream — into a scratch output, residual disabled, so
+// in-place residual updates are not applied twice — and caches the winner.  ~40 distinct shapes per pipeline.
+typedef std::tuple<int, int, int, int, int, int, int, int> TuneKey;
+static std::mutex g_tune_mutex;
+static std::map<TuneKey, int>& tune_cache() {
+    static std::map<TuneKey, int> m;
+    return m;
+}
+
+template <typename T>
+static int autotuned_cfg(const GemmArgs& g0, hipStream_t s) {
+    const int fallback = pick_cfg(g0.M, g0.N);
+    if (Tr<T>::kVec != 8 || g0.M <= 128 || tuning_get("gemm_cfg", 0) || !tuning_get("gemm_autotune", 1)) return fallback;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
+    const TuneKey key(Tr<T>::kDtype, g0.M, g0.N, g0.K, g0.conv_Cin, g0.conv_stride * 2 + g0.conv_up, g0.conv_H, g0.conv_W);
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        auto it = tune_cache().find(key);
+        if (it != tune_cache().end()) return it->second;
+    }
+    void* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)g0.M * g0.N * sizeof(T)) != hipSuccess) return fallback;
+    GemmArgs g = g0;
+    g.C = scratch; g.ldc = g0.N; g.residual = nullptr; g.epi &= ~SS_EPI_RESIDUAL;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int cands[3] = {8, 15, 10};
+    int best = fallback;
+    float best_ms = 1e30f;
+    for (int c : cands) {
+        if (gemm_dispatch_cfg<T>(c, g, s) != SS_OK) continue;   // warm-up (also faults pages in)
+        hipEventRecord(e0, s);
+        for (int r = 0; r < 3; ++r) gemm_dispatch_cfg<T>(c, g, s);
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(scratch);
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    tune_cache()[key] = best;
+    return best;
 }
 
 template <typename T>
@@ -473,7 +560,7 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
     g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
-    return gemm_dispatch_cfg<T>(pick_cfg(M, N), g, s);
+    return gemm_dispatch_cfg<T>(autotuned_cfg<T>(g, s), g, s);
 }
 
 // 3x3 convolution, padding 1, stride 1|2, optional fused nearest-2x upsample of the input, NHWC:
@@ -495,7 +582,7 @@ int conv3x3_launch(const void* x, const void* w, void* y, int64_t B, int64_t H, 
     g.conv_H = (int)H; g.conv_W = (int)Wd; g.conv_Cin = (int)Cin; g.conv_stride = (int)stride; g.conv_up = (int)up;
     g.conv_Ho = (int)Ho; g.conv_Wo = (int)Wo;
     if (g.M == 0) return SS_OK;
-    return gemm_dispatch_cfg<T>(pick_cfg(g.M, g.N), g, s);
+    return gemm_dispatch_cfg<T>(autotuned_cfg<T>(g, s), g, s);
 }
 
 int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,

@@ -320,7 +320,9 @@ class UNet2DConditionModel(nn.Module):
             h = ops.gemm(a, P[b + ".attn1.to_out.0.weight"], bias=P[b + ".attn1.to_out.0.bias"], residual=h)
             y = ops.layernorm(h, P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5)
             q = ops.gemm(y, P[b + ".attn2.to_q.weight"])
-            kv = ops.gemm(ctx2d, P[b + ".attn2.kv"])
+            kv = self._ctx_kv.get(b)
+            if kv is None:   # K/V of the 64 context tokens do not depend on the denoising step: once per image
+                kv = self._ctx_kv[b] = ops.gemm(ctx2d, P[b + ".attn2.kv"])
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
             h = ops.gemm(a, P[b + ".attn2.to_out.0.weight"], bias=P[b + ".attn2.to_out.0.bias"], residual=h)
             y = ops.layernorm(h, P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5)
@@ -350,6 +352,9 @@ class UNet2DConditionModel(nn.Module):
         ctx = encoder_hidden_states.to(dt).contiguous()
         Lctx = ctx.shape[1]
         ctx2d = ctx.view(B * Lctx, -1)
+        ckey = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(ctx.shape), dt, id(P))
+        if getattr(self, "_ctx_key", None) != ckey:       # new conditioning (new image): drop the cached cross-attn K/V
+            self._ctx_key, self._ctx_kv = ckey, {}
 
         x = ops.nchw_to_nhwc(sample.contiguous(), 8)                       # 4 -> 8 zero-padded channels
         h, _, _ = ops.conv3x3(x, P["conv_in.weight"], B, H, W, bias=P["conv_in.bias"])
@@ -594,6 +599,7 @@ class StableDiffusionXLPipeline:
                  output_type="pil", **kw):
         dev, dt = prompt_embeds.device, prompt_embeds.dtype
         lh, lw = height // 8, width // 8
+        self.unet._ctx_key = None            # new conditioning: recompute the cached cross-attention K/V
         self.scheduler.set_timesteps(num_inference_steps)
         sig, ts = self.scheduler.sigmas, self.scheduler.timesteps
         if latents is None:
