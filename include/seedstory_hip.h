@@ -40,7 +40,9 @@ enum {
     SS_EPI_BIAS = 1,      /* + bias[N]                                                   */
     SS_EPI_GELU = 2,      /* exact-erf GELU after bias (nn.GELU, qwen_visual.py:258-260)  */
     SS_EPI_RESIDUAL = 4,  /* out = residual + round_T(acc [+bias])                        */
-    SS_EPI_SILU_MUL = 8   /* GEMV only: y[n] = silu(acc[n]) * acc[n+N]  (LlamaMLP :190)   */
+    SS_EPI_SILU_MUL = 8,  /* GEMV only: y[n] = silu(acc[n]) * acc[n+N]  (LlamaMLP :190)   */
+    SS_EPI_GEGLU_PAIR = 16 /* GEMM only: W rows interleaved (value_i, gate_i); C[m][i] = (acc+b)[2i] * gelu_erf((acc+b)[2i+1]),
+                              C has N/2 columns (diffusers GEGLU fused into ff.net.0.proj)   */
 };
 
 const char* ss_last_error(void);

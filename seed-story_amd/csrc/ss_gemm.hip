@@ -211,6 +211,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
             }
+            if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2)
+                    if (n0 + r + 1 < N) Tr<T>::st(C + (int64_t)m * g.ldc + ((n0 + r) >> 1), v[r] * Tr<T>::rnd(gelu_erf(v[r + 1])));
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (n0 + r < N) Tr<T>::st(C + (int64_t)m * g.ldc + n0 + r, v[r]);
@@ -430,6 +436,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
             }
+            if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
+                const float o0 = v[0] * Tr<T>::rnd(gelu_erf(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_erf(v[3]));
+                if (n0 + 3 < N && ((g.ldc & 1) == 0)) {
+                    float pk[8] = {o0, o1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<uint32_t*>(C + (int64_t)m * g.ldc + (n0 >> 1)) = pack<T>(pk).x;
+                } else {
+                    if (n0 + 1 < N) Tr<T>::st(C + (int64_t)m * g.ldc + (n0 >> 1), o0);
+                    if (n0 + 3 < N) Tr<T>::st(C + (int64_t)m * g.ldc + (n0 >> 1) + 1, o1);
+                }
+                continue;
+            }
             if (n0 + 3 < N && ((g.ldc & 3) == 0)) {
                 float pk[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
                 const uint4 u = pack<T>(pk);
@@ -552,6 +569,8 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     SS_REQUIRE(K % V == 0 && lda % V == 0 && ldw % V == 0, "gemm: K/lda/ldw must be multiples of %d (K=%lld)", V,
                (long long)K);
     SS_REQUIRE(!(epi & SS_EPI_SILU_MUL), "gemm: SILU_MUL is a GEMV epilogue (use ss_silu_mul)");
+    SS_REQUIRE(!(epi & SS_EPI_GEGLU_PAIR) || (!(epi & (SS_EPI_GELU | SS_EPI_RESIDUAL)) && N % 2 == 0),
+               "gemm: GEGLU_PAIR cannot be combined with GELU/RESIDUAL and needs an even N");
     SS_REQUIRE(!(epi & SS_EPI_BIAS) || bias, "gemm: bias epilogue without bias");
     SS_REQUIRE(!(epi & SS_EPI_RESIDUAL) || residual, "gemm: residual epilogue without residual");
     if (M == 0 || N == 0) return SS_OK;

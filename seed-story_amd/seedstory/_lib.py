@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEDSTORY_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libseedstory_hip.so"))
 
 SS_F32, SS_BF16, SS_F16 = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SILU_MUL = 0, 1, 2, 4, 8
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_GEGLU_PAIR = 0, 1, 2, 4, 8, 16
 
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 i32p = C.POINTER(C.c_int32)

@@ -275,6 +275,12 @@ class UNet2DConditionModel(nn.Module):
             if k.endswith("attn1.to_q.weight"):
                 b = k[:-len("to_q.weight")]
                 P[b + "qkv"] = torch.cat([sd[b + "to_q.weight"], sd[b + "to_k.weight"], sd[b + "to_v.weight"]], 0).contiguous()
+            if k.endswith("ff.net.0.proj.weight"):   # GEGLU fused into the GEMM epilogue: interleave (value_i, gate_i) rows
+                b = k[:-len("weight")]
+                w, bb = sd[k], sd[b + "bias"]
+                d = w.shape[0] // 2
+                P[b + "pairs.weight"] = torch.stack([w[:d], w[d:]], dim=1).reshape(2 * d, w.shape[1]).contiguous()
+                P[b + "pairs.bias"] = torch.stack([bb[:d], bb[d:]], dim=1).reshape(2 * d).contiguous()
             if k.endswith("attn2.to_k.weight"):
                 b = k[:-len("to_k.weight")]
                 P[b + "kv"] = torch.cat([sd[b + "to_k.weight"], sd[b + "to_v.weight"]], 0).contiguous()
@@ -326,8 +332,8 @@ class UNet2DConditionModel(nn.Module):
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
             h = ops.gemm(a, P[b + ".attn2.to_out.0.weight"], bias=P[b + ".attn2.to_out.0.bias"], residual=h)
             y = ops.layernorm(h, P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5)
-            g = ops.gemm(y, P[b + ".ff.net.0.proj.weight"], bias=P[b + ".ff.net.0.proj.bias"])
-            h = ops.gemm(ops.geglu(g), P[b + ".ff.net.2.weight"], bias=P[b + ".ff.net.2.bias"], residual=h)
+            u = ops.gemm_geglu(y, P[b + ".ff.net.0.proj.pairs.weight"], P[b + ".ff.net.0.proj.pairs.bias"])
+            h = ops.gemm(u, P[b + ".ff.net.2.weight"], bias=P[b + ".ff.net.2.bias"], residual=h)
         return ops.gemm(h, P[n + ".proj_out.weight"], bias=P[n + ".proj_out.bias"], residual=x)
 
     @torch.no_grad()

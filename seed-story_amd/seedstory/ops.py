@@ -164,6 +164,17 @@ def gemm(a, w, bias=None, residual=None, gelu=False, out=None):
     return out
 
 
+def gemm_geglu(a, w_pairs, bias_pairs):
+    """a [M, K] @ w_pairs[2D, K]^T with rows interleaved (value_i, gate_i) -> [M, D] = value * gelu(gate)."""
+    _req(a); _req(w_pairs)
+    M, K = a.shape
+    N = w_pairs.shape[0]
+    out = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
+    check(lib().ss_gemm(p(a), p(w_pairs), p(out), M, N, K, K, K, N // 2, p(bias_pairs), None, 0,
+                        _lib.EPI_BIAS | _lib.EPI_GEGLU_PAIR, dt(a), stream()), "ss_gemm(geglu)")
+    return out
+
+
 def gemv(w, x, norm_w=None, eps=0.0, bias=None, residual=None, silu_mul=False):
     _req(w); _req(x)
     N, K = w.shape

@@ -218,3 +218,20 @@ def test_sdxl_adapter_generate_tiny():
     a, b = np.asarray(imgs[0]).astype(np.int32), np.asarray(imgs2[0]).astype(np.int32)
     # seed 42 -> same image; GroupNorm statistics use fp32 atomics (sum order varies): <= 1 uint8 level on a few pixels
     assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_geglu_epilogue(dtype):
+    """GEGLU fused into the ff.net.0.proj GEMM (interleaved value/gate rows) == separate GEMM + GEGLU."""
+    from seedstory import ops
+    M, K, D = 300, 256, 520
+    a = synth.normal_like(60, (M, K), 1.0, dtype=dtype)
+    w = synth.normal_like(61, (2 * D, K), 0.06, dtype=dtype)
+    b = synth.normal_like(62, (2 * D,), 0.3, dtype=dtype)
+    g = (a.float() @ w.float().t() + b.float()).to(dtype).float()
+    ref = g[:, :D] * F.gelu(g[:, D:]).to(dtype).float()
+    wp = torch.stack([w[:D], w[D:]], dim=1).reshape(2 * D, K).contiguous()
+    bp = torch.stack([b[:D], b[D:]], dim=1).reshape(2 * D).contiguous()
+    y = ops.gemm_geglu(a.to(DEV), wp.to(DEV), bp.to(DEV))
+    assert y.shape == (M, D)
+    assert rel(y, ref) < (2e-5 if dtype == torch.float32 else 6e-3)
