@@ -1,0 +1,189 @@
+"""MI355X-native story-generation driver — the flow of the reference's ``src/inference/gen_george.py``
+(load everything from the hydra-style YAMLs, then per story: ViT encode -> ``agent.generate`` ->
+``adapter.generate`` -> save JPEG, 8-image sliding window, 25 steps) on the drop-in modules of this repo.
+
+    PYTHONPATH=seed-story_amd python -m src.inference.gen_george --val data/json/val.jsonl        # real checkpoints
+    PYTHONPATH=seed-story_amd python -m src.inference.gen_george --synthetic --tiny --steps 4     # random weights
+
+Differences from the reference script, all behaviour-preserving: one ``main()`` instead of module-level code;
+token-id level context management (``seedstory.story.StoryContext``) instead of string surgery + full
+re-tokenisation; ``--window-mode sink`` switches the eviction policy to the multimodal attention sink on the
+KV slab (the reference's vis_george_sink.py computes it and then discards it, :316).
+"""
+import argparse
+import json
+import os
+import re
+
+import torch
+
+from seedstory import instantiate as I
+from seedstory.story import StoryContext
+
+BOI_TOKEN = '<img>'
+EOI_TOKEN = '</img>'
+IMG_TOKEN = '<img_{:05d}>'
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "configs")
+
+
+class SyntheticTokenizer:
+    """Stand-in used with --synthetic: ids 3..31999 are 'text', 32000..32065 the 66 image tokens."""
+    bos_token_id, eos_token_id = 1, 2
+
+    def __init__(self, vocab=32066):
+        self.vocab = vocab
+        self.img = list(range(vocab - 66, vocab))
+
+    def encode(self, s, add_special_tokens=False):
+        if s == BOI_TOKEN:
+            return [self.img[0]]
+        if s == EOI_TOKEN:
+            return [self.img[-1]]
+        if s.startswith(BOI_TOKEN):
+            return list(self.img)
+        return [3 + (hash(w) % (self.vocab - 70)) for w in s.split()]
+
+    def decode(self, ids, skip_special_tokens=False):
+        return " ".join("<%d>" % int(i) if int(i) >= self.vocab - 66 else "w%d" % int(i) for i in ids)
+
+
+def build(args, device, dtype):
+    if not args.synthetic:
+        tokenizer = I.instantiate(I.load(os.path.join(CFG, "tokenizer/clm_llama_tokenizer.yaml")))
+        transform = I.instantiate(I.load(os.path.join(CFG, "processer/qwen_448_transform.yaml")))
+        vit = I.instantiate(I.load(os.path.join(CFG, "visual_tokenizer/qwen_vitg_448.yaml"))).eval().to(device, dtype=dtype)
+        llm = I.instantiate(I.load(os.path.join(CFG, "clm_models/llama2chat7b_lora.yaml")), torch_dtype=args.dtype)
+        agent = I.instantiate(I.load(os.path.join(CFG, "clm_models/agent_7b_sft.yaml")), llm=llm).eval().to(device, dtype=dtype)
+        from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, UNet2DConditionModel
+        sched = EulerDiscreteScheduler.from_pretrained(args.sdxl, subfolder="scheduler")
+        vae = AutoencoderKL.from_pretrained(args.sdxl, subfolder="vae").to(device, dtype=dtype)
+        unet = UNet2DConditionModel.from_pretrained(args.sdxl, subfolder="unet").to(device, dtype=dtype)
+        adapter = I.instantiate(I.load(os.path.join(CFG, "detokenizer/detokenizer_sdxl_qwen_vit_adapted.yaml")), unet=unet)
+        adapter = adapter.to(device, dtype=dtype).eval()
+        disc = I.instantiate(I.load(os.path.join(CFG, "discrete_model/discrete_identity.yaml"))).to(device).eval()
+        adapter.init_pipe(vae=vae, scheduler=sched, visual_encoder=vit, image_transform=transform, discrete_model=disc,
+                          dtype=dtype, device=device)
+        return tokenizer, transform, vit, agent, adapter
+    # ---- synthetic weights (no checkpoints on this box) -------------------------------------------------
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, UNet2DConditionModel
+    from src.models.discrete_models import DiscreteModleIdentity
+    from src.models.qwen_visual import Resampler, VisionTransformerWithAttnPool
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    from src.models_clm.models import ContinuousLVLM
+    from src.models_ipa.adapter_modules import SDXLAdapter
+    from src.models_ipa.resampler import ResamplerXLV2
+    from src.processer.transforms import get_transform
+    t = args.tiny
+    H, heads, layers, inter, vocab = (256, 2, 2, 512, 1066) if t else (4096, 32, 32, 11008, 32066)
+    tokenizer = SyntheticTokenizer(vocab)
+    cfg = LlamaConfig(hidden_size=H, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                      vocab_size=vocab)
+    llm = LlamaForCausalLM(cfg).to(device, dtype=dtype).init_synthetic(0)
+    llm.use_kv_cache_head = False
+    rin = Resampler(grid_size=8, embed_dim=H, num_heads=heads, kv_dim=H).to(device, dtype=dtype).init_synthetic(1)
+    rout = Resampler(grid_size=16, embed_dim=H, num_heads=heads, kv_dim=H).to(device, dtype=dtype).init_synthetic(2)
+    agent = ContinuousLVLM(llm, rin, rout).eval()
+    if t:
+        vit = VisionTransformerWithAttnPool(image_size=224, patch_size=14, width=208, layers=2, heads=2, mlp_ratio=2.0,
+                                            n_queries=256, output_dim=H)
+    else:
+        vit = VisionTransformerWithAttnPool(image_size=448, patch_size=14, width=1664, layers=48, heads=16,
+                                            mlp_ratio=4.9231, output_dim=H)
+    vit = vit.to(device, dtype=dtype).init_synthetic(3)
+    import sys
+    unet_cfg = vae_cfg = None
+    if t:
+        unet_cfg = dict(in_channels=4, out_channels=4, block_out_channels=(64, 128, 256), layers_per_block=2,
+                        transformer_layers=(0, 1, 2), num_heads=(1, 2, 4), cross_attention_dim=128,
+                        addition_time_embed_dim=32, pooled_dim=80, norm_groups=32)
+        vae_cfg = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
+                       norm_groups=32, scaling_factor=0.13025)
+    unet = UNet2DConditionModel(unet_cfg).to(device, dtype=dtype).init_synthetic(4)
+    vae = AutoencoderKL(vae_cfg).to(device, dtype=dtype).init_synthetic(5)
+    rs = (ResamplerXLV2(dim=128, depth=2, dim_head=32, heads=4, num_queries=8, embedding_dim=H, output1_dim=48,
+                        output2_dim=80, ff_mult=4) if t else
+          ResamplerXLV2(dim=1024, depth=4, dim_head=64, heads=16, num_queries=64, embedding_dim=H, output1_dim=768,
+                        output2_dim=1280, ff_mult=4)).to(device, dtype=dtype).init_synthetic(6)
+    adapter = SDXLAdapter.from_pretrained(unet=unet, resampler=rs).eval()
+    size = 224 if t else 448
+    adapter.init_pipe(vae=vae, scheduler=EulerDiscreteScheduler(), visual_encoder=vit,
+                      image_transform=get_transform('clip', image_size=size, keep_ratio=False),
+                      discrete_model=DiscreteModleIdentity(), dtype=dtype, device=device)
+    return tokenizer, adapter.image_transform, vit, agent, adapter
+
+
+def run_story(args, j, question, image, tokenizer, transform, vit, agent, adapter, device, dtype):
+    save_folder = os.path.join(args.out, "val_%d" % j)
+    os.makedirs(save_folder, exist_ok=True)
+    boi = tokenizer.encode(BOI_TOKEN, add_special_tokens=False)[0]
+    eoi = tokenizer.encode(EOI_TOKEN, add_special_tokens=False)[0]
+    img_all = tokenizer.encode(BOI_TOKEN + ''.join(IMG_TOKEN.format(i) for i in range(64)) + EOI_TOKEN, add_special_tokens=False)
+    ctx = StoryContext(tokenizer.bos_token_id, boi, eoi, img_all[1:-1], window=args.window)
+    image_tensor = transform(image).unsqueeze(0).to(device, dtype=dtype)
+    with torch.no_grad():
+        ctx.start(tokenizer.encode(question, add_special_tokens=False), vit(image_tensor))   # gen_george.py:168-188
+    llama = agent.llm.base_model.model if hasattr(agent.llm, "base_model") else agent.llm
+    llama.use_kv_cache_head = False                                                         # :165
+    size = args.image_size
+    forced = None
+    for step in range(1, args.steps + 1):
+        if args.synthetic:   # random weights never emit <img>: force a caption + <img> (SURVEY section 8d schedule)
+            g = torch.Generator().manual_seed(1000 * j + step)
+            forced = torch.randint(3, 1000, (args.caption_tokens,), generator=g).tolist() + [boi]
+        ids_mask, emb_mask = ctx.masks(device)
+        out = agent.generate(tokenizer=tokenizer, input_ids=ctx.input_ids(device), image_embeds=ctx.image_embeds,
+                             embeds_cmp_mask=emb_mask, ids_cmp_mask=ids_mask, max_new_tokens=500, num_img_gen_tokens=64,
+                             forced_tokens=forced)
+        text = re.sub(r'\s*<[^>]*>\s*', ' ', out['text']).strip()
+        with open(os.path.join(save_folder, "text.txt"), "a+") as f:
+            f.write(text + "\n")
+        with open(os.path.join(save_folder, "token.txt"), "a+") as f:
+            f.write("context token: {}\n".format((1, len(ctx.ids))))
+        if not out['has_img_output']:
+            break
+        images = adapter.generate(image_embeds=out['img_gen_feat'], num_inference_steps=args.diffusion_steps,
+                                  height=size, width=size, input_image_size=transform.size)
+        images[0].save(os.path.join(save_folder, 'ori_{:02d}.jpg'.format(step)))
+        gen = out['generate_ids'].tolist()
+        cap = gen[:gen.index(boi)] if boi in gen else gen
+        ctx.append_step(cap, out['img_gen_feat'])                                           # :224, :231
+        if ctx.over_window():
+            ctx.evict_recompute()                                                           # :235-239
+    return save_folder
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--val", default="data/json/val.jsonl")
+    ap.add_argument("--image-root", default="data/image/george_full")
+    ap.add_argument("--sdxl", default="pretrained/stable-diffusion-xl-base-1.0")
+    ap.add_argument("--out", default="output")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--steps", type=int, default=24)             # story_len 25 (:205)
+    ap.add_argument("--window", type=int, default=8)             # window_size (:206)
+    ap.add_argument("--diffusion-steps", type=int, default=50)   # :210
+    ap.add_argument("--image-size", type=int, default=1024)
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--caption-tokens", type=int, default=48)
+    ap.add_argument("--stories", type=int, default=1)
+    args = ap.parse_args()
+    device = "cuda:0"
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    tokenizer, transform, vit, agent, adapter = build(args, device, dtype)
+    from PIL import Image
+    if args.synthetic:
+        data = [{"images": [None], "captions": ["a synthetic story question number %d" % i]} for i in range(args.stories)]
+    else:
+        data = [json.loads(l) for l in open(args.val)]
+    for j, d in enumerate(data):
+        if args.synthetic:
+            image = Image.new("RGB", (320, 240), (40 * j % 255, 120, 200))
+        else:
+            image = Image.open(os.path.join(args.image_root, d['images'][0])).convert('RGB')
+        folder = run_story(args, j, d['captions'][0], image, tokenizer, transform, vit, agent, adapter, device, dtype)
+        print("story", j, "->", folder)
+
+
+if __name__ == "__main__":
+    main()

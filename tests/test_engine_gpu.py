@@ -222,3 +222,57 @@ def test_full_width_layer_properties():
     c.prefill(emb[ids[:100]])
     c.generate(21, last_prompt_id=int(ids[99]), forced=ids[100:].tolist() + [5])
     assert torch.equal(c.hidden_rows[:20], b.hidden_rows[:20])
+
+
+def test_attention_sink_continuation_matches_oracle(golden):
+    """Multimodal attention sink (clean spec of vis_george_sink.py:266-295): evict the oldest image on the KV
+    slab, then continue with window-relative positions; hidden states must equal the oracle run on the gathered
+    cache (keys keep their original rotary phase)."""
+    from seedstory.llama import LlamaEngine
+    from seedstory.story import StoryContext
+    g, meta = golden
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    eng = LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"],
+                      vocab=d["vocab"], dtype=torch.float32, device=DEV, cache_cap=512, max_new=64, max_prefill_rows=256,
+                      img_ids=_img_ids(meta))
+    emb = wd["model.embed_tokens.weight"]
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    ids_img = _img_ids(meta)
+    ctx = StoryContext(bos_id=1, boi_id=ids_img[0], eoi_id=ids_img[-1], img_placeholder_ids=ids_img[1:-1], window=1)
+    ctx.start(synth.randint(70, (6,), 3, 250).tolist(), torch.zeros(1, 4, 8))
+    ctx.append_step(synth.randint(71, (5,), 3, 250).tolist(), torch.zeros(1, 4, 8))
+    ids = torch.tensor(ctx.ids)
+    S = len(ctx.ids)                                              # 1 + 6 + 66 + 5 + 66 = 144
+    eng.reset()
+    eng.prefill(emb[ids])
+    _, _, kv = O.llama_forward(wd, dims, emb[ids].unsqueeze(0), torch.arange(S).unsqueeze(0))
+    b, e = ctx.ids.index(ids_img[0]), ctx.ids.index(ids_img[-1])
+    keep, new_sink = O.sink_evict_indices(S, b, e, 0, True)
+    kv_len = ctx.evict_sink(eng, S)
+    assert kv_len == len(keep) == eng.lengths()[0] and ctx.sink_len == new_sink
+    window_len = len(ctx.ids)
+    eng.set_lengths(kv_len, window_len)                           # new queries: window-relative positions
+    new_ids = synth.randint(72, (9,), 3, 250)
+    hid = eng.prefill(emb[new_ids], want_hidden=True)
+    past = [(k[:, :, keep], v[:, :, keep]) for k, v in kv]
+    pos = torch.arange(window_len, window_len + 9).unsqueeze(0)
+    _, ref_hid, _ = O.llama_forward(wd, dims, emb[new_ids].unsqueeze(0), pos, past)
+    assert rel(hid, ref_hid[0]) < 1e-4
+
+
+def test_gen_george_driver_synthetic_tiny(tmp_path):
+    """The story driver end to end (ViT -> agent.generate -> adapter.generate -> JPEG, window eviction) on
+    tiny random-weight models: 4 steps with a 2-image window (forces two recompute evictions)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "seed-story_amd"))
+    out = subprocess.run([sys.executable, "-m", "src.inference.gen_george", "--synthetic", "--tiny", "--steps", "4",
+                          "--window", "2", "--diffusion-steps", "2", "--image-size", "64", "--caption-tokens", "5",
+                          "--out", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.join(root, "seed-story_amd"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    folder = tmp_path / "val_0"
+    assert sorted(p.name for p in folder.glob("ori_*.jpg")) == ["ori_01.jpg", "ori_02.jpg", "ori_03.jpg", "ori_04.jpg"]
+    lens = [int(l.split(",")[1].strip(" )\n")) for l in open(folder / "token.txt")]
+    assert lens[0] == 1 + 6 + 66 and lens[1] == lens[0] + 5 + 66 and lens[3] <= lens[1] + 5 + 66   # 6-word question; window holds
