@@ -226,11 +226,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("SS_BENCH_SINGLE_DEVICE"):      # flow test of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if os.environ.get("SS_BENCH_SINGLE_DEVICE"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = torch.bfloat16
     global STORY_LEN
     if args.mllm_only:
@@ -263,7 +268,7 @@ def main():
     barrier()
     dt_s = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt_s], device=device, dtype=torch.float64)
+        t = torch.tensor([dt_s], dtype=torch.float64, device="cpu" if os.environ.get("SS_BENCH_SINGLE_DEVICE") else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
 

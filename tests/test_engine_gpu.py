@@ -276,3 +276,21 @@ def test_gen_george_driver_synthetic_tiny(tmp_path):
     assert sorted(p.name for p in folder.glob("ori_*.jpg")) == ["ori_01.jpg", "ori_02.jpg", "ori_03.jpg", "ori_04.jpg"]
     lens = [int(l.split(",")[1].strip(" )\n")) for l in open(folder / "token.txt")]
     assert lens[0] == 1 + 6 + 66 and lens[1] == lens[0] + 5 + 66 and lens[3] <= lens[1] + 5 + 66   # 6-word question; window holds
+
+
+def test_vis_george_sink_driver_synthetic_tiny(tmp_path):
+    """Story-visualisation driver with the multimodal attention sink live on the KV slab: 5 steps, 2-image window
+    (three sink evictions), continuation through past_key_values / kv_cache_head."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "seed-story_amd"))
+    out = subprocess.run([sys.executable, "-m", "src.inference.vis_george_sink", "--synthetic", "--tiny", "--steps", "5",
+                          "--window", "2", "--diffusion-steps", "2", "--image-size", "64", "--caption-tokens", "7",
+                          "--out", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.join(root, "seed-story_amd"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = open(tmp_path / "val_0" / "token.txt").read().strip().split("\n")
+    assert len(lines) == 5
+    sinks = [int(l.rsplit("sink:", 1)[1]) for l in lines]
+    assert sinks[:2] == [0, 0] and sinks[2] == 28 and sinks[3] == 52 and sinks[4] == 76     # 4 + 24 per evicted image
+    assert len(list((tmp_path / "val_0").glob("ori_*.jpg"))) == 5

@@ -185,7 +185,7 @@ def bench_gemm_unet():
         w = torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         row = dict(M=M, N=N, K=K)
-        for cfg in (8, 10, 12, 13, 14, 15, 16, 17):
+        for cfg in (8, 10, 15):
             _lib.set_tuning("gemm_cfg", cfg)
             ms = timeit(lambda: ops.gemm(a, w, out=out), iters=10)
             row["cfg%d" % cfg] = round(2.0 * M * N * K / ms / 1e9)

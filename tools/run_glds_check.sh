@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for c in 12 13 14 15 16 17; do python - <<PY
+for c in 8 10 15; do python - <<PY
 import sys; sys.path.insert(0,'seed-story_amd'); sys.path.insert(0,'oracle'); sys.path.insert(0,'tests')
 import torch, synth
 from seedstory import _lib, ops
