@@ -20,8 +20,16 @@ feature -> ``adapter.generate`` (gen_george.py:210): ResamplerXLV2 conditioning 
 CFG) + Euler update} + VAE decode to a uint8 1024x1024 image.  The first step of every story also
 encodes the 448x448 input image with ViT-G (and the constant all-zeros negative image once).
 
+``--stories-per-gpu S`` (default 4): S independent stories are resident on each GPU and advance in
+lock-step — their decode iterations share ONE sweep of the 13.2 GB of LLaMA weights per token
+(ss_llama_generate_batch, HBM bytes per generated token / S) and their S images are denoised together
+(UNet batch 2S).  One bench *step* is then one lock-step round = S story-steps; every story still
+computes exactly what a batch-1 run computes (tests/test_engine_gpu.py::
+test_llama_slot_batched_decode_equals_single).  ``--stories-per-gpu 1`` is the reference's batch-1
+latency configuration.
+
 N > 1: one process per GPU, independent stories per rank (SURVEY §8e story-level replicas, no
-data-path collective), weak scaling; value = steps of all ranks / max-over-ranks time.
+data-path collective), weak scaling; value = story-steps of all ranks / max-over-ranks time.
 """
 import argparse
 import json
@@ -60,7 +68,7 @@ def build_detokenizer(device, dtype, vit):
     return adapter
 
 
-def build_models(device, dtype):
+def build_models(device, dtype, n_seq=1):
     from seedstory.llama import LlamaEngine
     from src.models.qwen_visual import Resampler, VisionTransformerWithAttnPool
     torch.manual_seed(1234)
@@ -73,7 +81,7 @@ def build_models(device, dtype):
     eng = LlamaEngine.from_prebuilt(embed=rnd(VOCAB, H), lm_head=rnd(VOCAB, H), final_norm=ones(H), layers=layers,
                                     hidden=H, n_heads=NH, n_layers=NL, inter=INTER, vocab=VOCAB, dtype=dtype,
                                     device=device, cache_cap=1024, max_new=128, max_prefill_rows=640, img_ids=IMG_IDS,
-                                    eos_id=EOS)
+                                    eos_id=EOS, n_seq=n_seq)
     rin = Resampler(grid_size=8, embed_dim=H, num_heads=32, kv_dim=H).to(device=device, dtype=dtype).init_synthetic(1)
     rout = Resampler(grid_size=16, embed_dim=H, num_heads=32, kv_dim=H).to(device=device, dtype=dtype).init_synthetic(2)
     vit = VisionTransformerWithAttnPool(image_size=448, patch_size=14, width=1664, layers=48, heads=16,
@@ -103,37 +111,53 @@ class Story:
         return cap + IMG_IDS + [EOS]
 
 
-def run_step(st, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
+def run_round(sts, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
+    """One multimodal step of every resident story (slot b of the engine = story sts[b]); all stories of
+    a round are at the same step index.  With one story this is exactly one ``agent.generate`` +
+    ``adapter.generate`` of gen_george.py."""
     from seedstory import ops
-    dev = st.device
-    if st.step == 0:
-        st.image_embeds = vit(st.image)                                   # [1,256,4096]  gen_george.py:187-188
-    ids = torch.tensor(st.ids, dtype=torch.int32, device=dev)
-    emb = ops.gather_rows(eng.embed, ids)                                 # models.py:127
-    lm = rin(st.image_embeds)                                             # [Nimg,64,H]   models.py:133
-    pos = [i + 1 for i, t in enumerate(st.ids) if t == IMG_IDS[0]]
-    idx = torch.tensor([p + j for p in pos for j in range(64)], dtype=torch.int32, device=dev)
-    ops.scatter_rows_(emb, idx, lm.reshape(-1, H))                        # models.py:135
-    S = len(st.ids)
-    if kv_reuse and st.step > 0:
-        keep = S - 65                                                     # ... caption + <img> stay cached
-        eng.set_lengths(keep, keep)
-        eng.prefill(emb[keep:])
+    dev = sts[0].device
+    for b, st in enumerate(sts):
+        eng.select(b)
+        if st.step == 0:
+            st.image_embeds = vit(st.image)                               # [1,256,4096]  gen_george.py:187-188
+        ids = torch.tensor(st.ids, dtype=torch.int32, device=dev)
+        emb = ops.gather_rows(eng.embed, ids)                             # models.py:127
+        lm = rin(st.image_embeds)                                         # [Nimg,64,H]   models.py:133
+        pos = [i + 1 for i, t in enumerate(st.ids) if t == IMG_IDS[0]]
+        idx = torch.tensor([p + j for p in pos for j in range(64)], dtype=torch.int32, device=dev)
+        ops.scatter_rows_(emb, idx, lm.reshape(-1, H))                    # models.py:135
+        S = len(st.ids)
+        if kv_reuse and st.step > 0:
+            keep = S - 65                                                 # ... caption + <img> stay cached
+            eng.set_lengths(keep, keep)
+            eng.prefill(emb[keep:])
+        else:
+            eng.reset()
+            eng.prefill(emb)
+    forced = [st.forced() for st in sts]
+    if len(sts) == 1:
+        ns = [eng.generate(500, sts[0].ids[-1], forced[0])]               # max_new_tokens=500 (gen_george.py:194)
     else:
-        eng.reset()
-        eng.prefill(emb)
-    forced = st.forced()
-    n = eng.generate(500, st.ids[-1], forced)                             # max_new_tokens=500 (gen_george.py:194)
-    assert n == T_GEN, n
+        ns = eng.generate_batch(500, [st.ids[-1] for st in sts], forced)  # the same loop, all slots per weight sweep
+    assert all(n == T_GEN for n in ns), ns
     e = CAPTION + 65                                                      # index of </img> in the generated ids
-    feats = eng.hidden_rows[e - 64:e].unsqueeze(0).contiguous()           # models.py:197
-    img_gen_feat = rout(feats)                                            # models.py:205  [1,256,4096]
+    feats = torch.stack([eng.select(b).hidden_rows[e - 64:e] for b in range(len(sts))]).contiguous()   # models.py:197
+    img_gen_feat = rout(feats)                                            # models.py:205  [S,256,4096]
     if adapter is not None:                                               # gen_george.py:210 (30 steps: BASELINE)
-        st.last_image = adapter.generate(image_embeds=img_gen_feat, num_inference_steps=steps, output_type="pt")
-    st.image_embeds = torch.cat([st.image_embeds, img_gen_feat], dim=0)   # gen_george.py:224
-    st.ids = st.ids + forced[:CAPTION] + IMG_IDS                          # prompt + text + image_tokens (:231)
-    st.step += 1
+        imgs = adapter.generate(image_embeds=img_gen_feat, num_inference_steps=steps, output_type="pt")
+        imgs = imgs.unsqueeze(0) if len(sts) == 1 else imgs
+    for b, st in enumerate(sts):
+        if adapter is not None:
+            st.last_image = imgs[b]
+        st.image_embeds = torch.cat([st.image_embeds, img_gen_feat[b:b + 1]], dim=0)   # gen_george.py:224
+        st.ids = st.ids + forced[b][:CAPTION] + IMG_IDS                   # prompt + text + image_tokens (:231)
+        st.step += 1
     return img_gen_feat
+
+
+def run_step(st, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
+    return run_round([st], eng, rin, rout, vit, kv_reuse, adapter, steps)
 
 
 def cpu_baseline(seconds_budget=25.0, with_sdxl=True, diffusion_steps=30):
@@ -217,6 +241,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mllm-only", action="store_true", help="BASELINE configs[1]: no SDXL render, 3-pair stories")
     ap.add_argument("--diffusion-steps", type=int, default=30)
+    ap.add_argument("--stories-per-gpu", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="stories resident per GPU, advanced in lock-step (1 = the reference's batch-1 loop)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,7 +266,8 @@ def main():
     global STORY_LEN
     if args.mllm_only:
         STORY_LEN = 3
-    eng, rin, rout, vit = build_models(device, dtype)
+    SPG = args.stories_per_gpu
+    eng, rin, rout, vit = build_models(device, dtype, SPG)
     adapter = None if args.mllm_only else build_detokenizer(device, dtype, vit)
 
     def barrier():
@@ -250,17 +277,19 @@ def main():
         torch.cuda.synchronize()
 
     story_no = [rank * 100003]
-    st = [None]
+    sts = [None]
 
     def one_step():
-        if st[0] is None or st[0].step >= STORY_LEN:
-            story_no[0] += 1
-            st[0] = Story(story_no[0], device)
-        return run_step(st[0], eng, rin, rout, vit, args.kv_reuse, adapter, args.diffusion_steps)
+        if sts[0] is None or sts[0][0].step >= STORY_LEN:
+            sts[0] = []
+            for _ in range(SPG):
+                story_no[0] += 1
+                sts[0].append(Story(story_no[0], device))
+        return run_round(sts[0], eng, rin, rout, vit, args.kv_reuse, adapter, args.diffusion_steps)
 
     for _ in range(args.warmup):
         one_step()
-    st[0] = None  # timed region starts at a story boundary
+    sts[0] = None  # timed region starts at a story boundary
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -275,7 +304,8 @@ def main():
     # ---- roofline of the dominant kernel (decode GEMV, HBM-bound), measured live with HIP events ----
     roof = None
     if rank == 0:
-        eng.set_lengths(343, 343)
+        for b in range(SPG):
+            eng.select(b).set_lengths(343, 343)
         prof = eng.profile_decode(8)
         # dominant kernel: ss::gemv_kernel<bf16,8,2> (65 launches/token: qkv, o, gate|up x32 + lm_head)
         per_launch_bytes = prof["gemv_bytes"] / prof["gemv_launches"]
@@ -291,7 +321,8 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "ss::gemv_kernel<bf16_t,8,2,false>",
+                "kernel": ("ss::gemv_kernel<bf16_t,8,2,%d>" % SPG) if SPG <= 2 else ("ss::gemv_ldsx_kernel<bf16_t,2,%d>" % SPG),
+                "slots_per_sweep": SPG,
                 "launches_per_token": prof["gemv_launches"], "bytes_per_launch": round(per_launch_bytes),
                 "avg_launch_us": round(per_launch_ms * 1e3, 3),
                 "also": {"gemv_ldsx_kernel(down proj) GB/s": round(down, 1),
@@ -300,11 +331,13 @@ def main():
                          "token_ms_eager": round(prof["token_ms"], 4), "attn_ms": round(prof["attn_ms"], 4),
                          "misc_ms": round(prof["misc_ms"], 4)}}
     if rank == 0 and adapter is not None:
-        # MFMA-bound half: one SDXL-base UNet forward (batch 2 = CFG pair, 128x128 latents), HIP events on the stream
-        x = torch.randn(2, 4, 128, 128, device=device, dtype=dtype)
-        ctx = torch.randn(2, 64, 2048, device=device, dtype=dtype)
-        cond = {"text_embeds": torch.randn(2, 1280, device=device, dtype=dtype),
-                "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)}
+        # MFMA-bound half: one SDXL-base UNet forward (batch 2S = CFG pairs of the S resident stories, 128x128
+        # latents), HIP events on the stream
+        UB = 2 * SPG
+        x = torch.randn(UB, 4, 128, 128, device=device, dtype=dtype)
+        ctx = torch.randn(UB, 64, 2048, device=device, dtype=dtype)
+        cond = {"text_embeds": torch.randn(UB, 1280, device=device, dtype=dtype),
+                "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * UB, dtype=torch.float32)}
         adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -313,19 +346,19 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
-        flops = 2 * 6.747e12                                   # 3.3735 TMAC per sample per forward
+        flops = UB * 6.747e12                                  # 3.3735 TMAC per sample per forward
         roof_mllm = roof
         roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": None,
                 "kernel": "SDXL UNet forward (ss::gemm_kernel<bf16,*> incl. implicit-GEMM conv3x3 + ss::flash_attn_kernel<bf16,64>)",
-                "flops_per_forward": flops, "forward_ms": round(ms, 3),
-                "note": "the step is 60 UNet forwards (MFMA-bound) + 115 decode tokens (HBM-bound): see mllm_decode_gemv",
+                "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
+                "note": "a round is 30 UNet forwards of batch %d (MFMA-bound) + 115 decode tokens for %d slots (HBM-bound): see mllm_decode_gemv" % (UB, SPG),
                 "mllm_decode_gemv": roof_mllm}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(with_sdxl=not args.mllm_only, diffusion_steps=args.diffusion_steps)
     if rank == 0:
-        total_steps = args.steps * world
+        total_steps = args.steps * world * SPG
         if args.mllm_only:
             workload = ("BASELINE configs[1]: LLaMA-7B MLLM (prefill S=115/229/343 + 115 greedy decode iterations) + Qwen "
                         "ViT-G encode per story + input/output Resampler regression, bf16, 3 image-text pairs, no SDXL")
@@ -339,10 +372,13 @@ def main():
         out = {"metric": metric,
                "value": round(total_steps / dt_s, 4), "unit": "story-steps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True,
+               "story_steps_per_step": SPG,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload, "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
-                          "parallelism": "story replicas x%d" % world},
+                          "stories_per_gpu": SPG,
+                          "step_definition": "one lock-step round of the %d resident stories = %d story-steps" % (SPG, SPG),
+                          "parallelism": "story replicas x%d, %d lock-step story slots per GPU" % (world, SPG)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

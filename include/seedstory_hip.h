@@ -147,6 +147,12 @@ int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t
  * [2N, K] = [gate; up], y[n] = silu(gate·x) * (up·x)), SS_EPI_BIAS.  K % 8 == 0. */
 int ss_gemv(const void* W, const void* x, void* y, int64_t N, int64_t K, const void* norm_w, float eps,
             const void* bias, const void* residual, int epilogue, int dtype, void* stream);
+/* The same projection for nb <= 4 rows at once (the lock-step decode of nb story slots):
+ * x [nb, K], y / residual [nb, N] contiguous.  W is swept ONCE; every 16-byte weight pack is
+ * dotted with all nb activation slices.  Row b equals ss_gemv on row b. */
+int ss_gemv_batched(const void* W, const void* x, void* y, int64_t N, int64_t K, int64_t nb,
+                    const void* norm_w, float eps, const void* bias, const void* residual, int epilogue,
+                    int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sampling: lm_head logits -> AutoImageTokenGenerationProcessor -> greedy argmax
@@ -174,6 +180,8 @@ typedef struct ss_llama_config {
     int32_t max_new;     /* capacity of the generated-token / hidden-state ring */
     int32_t n_img_ids;   /* 66 for SEED-Story */
     int32_t eos_id;
+    int32_t n_seq;       /* sequence slots (independent stories decoded in lock-step, sharing one
+                            sweep of the weights per token); 0 or 1 = the reference's batch-1 loop */
 } ss_llama_config;
 
 /* Per-layer weights, all [out, in] row-major in the model dtype, LoRA already merged
@@ -200,7 +208,12 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
                     ss_llama** out);
 void ss_llama_destroy(ss_llama* h);
 
-/* Device pointers into the engine's workspace (views for the Python side):
+/* Select the sequence slot (0 <= seq < n_seq) that ss_llama_buffer / set_lengths / get_lengths /
+ * kv_gather / prefill / generate address.  Slots have private KV caches, logits, token and hidden
+ * rings; they share the weights and the activation scratch.  Default slot 0. */
+int ss_llama_select(ss_llama* h, int32_t seq);
+
+/* Device pointers into the engine's workspace (views for the Python side), for the selected slot:
  * which: 0 = K cache [n_layers, n_heads, cache_cap, hd], 1 = V cache (same shape),
  * 2 = generated ids int32[max_new], 3 = hidden rows [max_new, hidden] (post final norm,
  * row j = state whose input token was generated id j; models.py:182-184),
@@ -233,7 +246,17 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
 int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, const int32_t* host_forced,
                       int64_t n_forced, int64_t* host_n_generated, void* stream);
 
-/* Per-kernel-class device time of one decode token, measured with a hipEvent pair around EVERY
+/* The same loop for all n_seq slots at once: every decode projection sweeps the weights ONCE and
+ * dots each pack with all slots' activations (HBM bytes per generated token fall as 1/n_seq).
+ * Per slot b: last_prompt_ids[b], forced tokens host_forced[b*forced_ld .. +n_forced[b]) (both
+ * optional), active[b] == 0 leaves the slot untouched (NULL = all active).  Slots stop
+ * independently at EOS / n_steps; host_n_generated[n_seq] receives the per-slot token counts.
+ * After the call the logits buffer of a slot that stopped early is undefined. */
+int ss_llama_generate_batch(ss_llama* h, int64_t n_steps, const int32_t* last_prompt_ids,
+                            const int32_t* host_forced, int64_t forced_ld, const int64_t* n_forced,
+                            const int32_t* active, int64_t* host_n_generated, void* stream);
+
+/* Per-kernel-class device time of one decode token (all n_seq slots together), measured with a hipEvent pair around EVERY
  * launch of un-captured (eager) decode steps on `stream`, averaged over n_tokens:
  * out_ms[0] = sum over the K=hidden GEMV launches (qkv, o, gate|up per layer + lm_head:
  *             ss::gemv_kernel), [1] = attention (+split merge), [2] = sum over the down-projection

@@ -513,10 +513,26 @@ struct DecodeArgs {
     const int32_t* done_flag;
     int hd, n_heads, cap, nsplit;
     float scale;
+    // sequence batch (blockIdx.z): element / int strides between consecutive sequences
+    int nb, state_stride;
+    int64_t q_stride, cache_stride, part_stride, out_stride;
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a0) {
+    DecodeArgs a = a0;
+    {   // select this block's sequence
+        const int b = blockIdx.z;
+        const int64_t so = (int64_t)b * a.state_stride;
+        if (a.done_flag) a.done_flag += so;
+        a.kv_len_dev += so;
+        if (a.pos_dev) a.pos_dev += so;
+        if (a.q) a.q = (const T*)a.q + b * a.q_stride;
+        if (a.qkv_raw) a.qkv_raw = (const T*)a.qkv_raw + b * a.q_stride;
+        a.kc = (T*)a.kc + b * a.cache_stride;
+        a.vc = (T*)a.vc + b * a.cache_stride;
+        a.part += b * a.part_stride;
+    }
     constexpr int V = Tr<T>::kVec;
     constexpr int KPT = 4;  // keys per thread per sub-chunk
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -623,8 +639,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
 
 template <typename T, int NS>
 __global__ void attn_combine_kernel(const float* __restrict__ part, T* __restrict__ out,
-                                    const int32_t* __restrict__ done_flag, int hd) {
-    if (done_flag && *done_flag) return;
+                                    const int32_t* __restrict__ done_flag, int hd, int state_stride,
+                                    int64_t part_stride, int64_t out_stride) {
+    const int b = blockIdx.y;
+    if (done_flag && done_flag[(int64_t)b * state_stride]) return;
+    part += b * part_stride;
+    out += b * out_stride;
     const int h = blockIdx.x, d = threadIdx.x;
     const float* rec = part + (int64_t)h * NS * (hd + 2);
     float ms[NS], ls[NS], os[NS];
@@ -662,11 +682,14 @@ int attn_decode_launch(const DecodeArgs& a0, void* out, int64_t n_heads, int64_t
     a.scale = 1.0f / sqrtf((float)hd);
     const int NKG = 256 / (int)(hd / V);
     const size_t lds = (size_t)NKG * (hd + 2) * sizeof(float);
-    hipLaunchKernelGGL(attn_decode_kernel<T>, dim3((unsigned)n_heads, (unsigned)a.nsplit), dim3(256), lds, s, a);
+    if (a.nb < 1) a.nb = 1;
+    hipLaunchKernelGGL(attn_decode_kernel<T>, dim3((unsigned)n_heads, (unsigned)a.nsplit, (unsigned)a.nb), dim3(256),
+                       lds, s, a);
     SS_LAUNCH_CHECK("attn_decode");
 #define SS_COMBINE(NS)                                                                                          \
-    hipLaunchKernelGGL((attn_combine_kernel<T, NS>), dim3((unsigned)n_heads), dim3((unsigned)hd), 0, s,          \
-                       (const float*)a.part, (T*)out, a.done_flag, (int)hd)
+    hipLaunchKernelGGL((attn_combine_kernel<T, NS>), dim3((unsigned)n_heads, (unsigned)a.nb), dim3((unsigned)hd), 0, \
+                       s, (const float*)a.part, (T*)out, a.done_flag, (int)hd, a.state_stride, a.part_stride,       \
+                       a.out_stride)
     switch (a.nsplit) {
         case 4: SS_COMBINE(4); break;
         case 8: SS_COMBINE(8); break;
@@ -686,14 +709,21 @@ int attn_decode_dev(const void* q, const void* kc, const void* vc, void* out, vo
     a.q = q; a.qkv_raw = nullptr; a.kc = (void*)kc; a.vc = (void*)vc; a.cos_t = a.sin_t = nullptr;
     a.part = (float*)ws; a.kv_len_dev = kv_len_dev; a.pos_dev = nullptr; a.done_flag = done_flag;
     a.hd = (int)hd; a.n_heads = (int)n_heads; a.cap = (int)cache_cap; a.nsplit = 0; a.scale = 0.f;
+    a.nb = 1; a.state_stride = 0; a.q_stride = a.cache_stride = a.part_stride = a.out_stride = 0;
     return SS_DISPATCH(dtype, attn_decode_launch, a, out, n_heads, hd, s);
 }
 
 // fused: pre-RoPE qkv row; rotates q/k, appends k/v at slot *kv_len_dev, attends over kv_len+1 keys
+// nb sequences: qkv rows 3*E apart, caches cache_stride elements apart, state words state_stride ints apart,
+// outputs E apart, partial records one workspace slab (ss_attn_decode_workspace_bytes) apart.
 int attn_decode_fused_dev(const void* qkv_raw, void* kc, void* vc, const void* cos_t, const void* sin_t, void* out,
                           void* ws, const int32_t* kv_len_dev, const int32_t* pos_dev, const int32_t* done_flag,
-                          int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype, hipStream_t s) {
+                          int64_t n_heads, int64_t hd, int64_t cache_cap, int nb, int state_stride,
+                          int64_t cache_stride, int dtype, hipStream_t s) {
     DecodeArgs a;
+    a.nb = nb; a.state_stride = state_stride; a.q_stride = 3 * n_heads * hd; a.cache_stride = cache_stride;
+    a.part_stride = (int64_t)(ss_attn_decode_workspace_bytes(n_heads, hd) / sizeof(float));
+    a.out_stride = n_heads * hd;
     a.q = nullptr; a.qkv_raw = qkv_raw; a.kc = kc; a.vc = vc; a.cos_t = cos_t; a.sin_t = sin_t;
     a.part = (float*)ws; a.kv_len_dev = kv_len_dev; a.pos_dev = pos_dev; a.done_flag = done_flag;
     a.hd = (int)hd; a.n_heads = (int)n_heads; a.cap = (int)cache_cap; a.nsplit = 0; a.scale = 0.f;

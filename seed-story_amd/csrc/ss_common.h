@@ -26,12 +26,15 @@ struct f16_t { uint16_t v; };
 
 // ---- scalar conversions ---------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-// round-to-nearest-even fp32 -> bf16 (matches torch's float->bfloat16 cast; NaN kept quiet)
+// round-to-nearest-even fp32 -> bf16 (matches torch's float->bfloat16 cast; NaN stays a quiet NaN):
+// gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), one VALU op per PAIR of values
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_bits(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
     _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)b);
@@ -89,10 +92,8 @@ template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 template <> __device__ __forceinline__ uint4 pack<bf16_t>(const float* f) {
-    return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
-                      f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
-                      f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
-                      f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+    return make_uint4(f32x2_to_bf16x2_bits(f[0], f[1]), f32x2_to_bf16x2_bits(f[2], f[3]),
+                      f32x2_to_bf16x2_bits(f[4], f[5]), f32x2_to_bf16x2_bits(f[6], f[7]));
 }
 template <> __device__ __forceinline__ uint4 pack<f16_t>(const float* f) {
     return make_uint4(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16),

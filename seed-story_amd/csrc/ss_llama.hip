@@ -24,6 +24,9 @@ namespace ss {
 
 int gemv_dev(const void* W, const void* x, void* y, int64_t N, int64_t K, const void* norm_w, float eps,
              const void* bias, const void* residual, int epi, const int32_t* done_flag, int dtype, hipStream_t s);
+int gemv_batched_dev(const void* W, const void* x, void* y, int64_t N, int64_t K, const void* norm_w, float eps,
+                     const void* bias, const void* residual, int epi, const int32_t* done_flag, int done_stride,
+                     int nb, int64_t x_ld, int64_t y_ld, int64_t res_ld, int dtype, hipStream_t s);
 int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
              int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, int dtype, hipStream_t s);
 int rope_kv_append_dev(const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
@@ -31,21 +34,31 @@ int rope_kv_append_dev(const void* qkv, void* q_out, void* kc, void* vc, const v
                        int64_t cache_cap, int dtype, hipStream_t s);
 int attn_decode_fused_dev(const void* qkv_raw, void* kc, void* vc, const void* cos_t, const void* sin_t, void* out,
                           void* ws, const int32_t* kv_len_dev, const int32_t* pos_dev, const int32_t* done_flag,
-                          int64_t n_heads, int64_t hd, int64_t cache_cap, int dtype, hipStream_t s);
+                          int64_t n_heads, int64_t hd, int64_t cache_cap, int nb, int state_stride,
+                          int64_t cache_stride, int dtype, hipStream_t s);
 
 // device state words
 enum { ST_KV_LEN = 0, ST_POS = 1, ST_NGEN = 2, ST_DONE = 3, ST_LAST = 4, ST_NFORCED = 5, ST_LIMIT = 6, ST_EOS = 7 };
 
 // ---- engine kernels ---------------------------------------------------------------------------
 
-// sample -> (forced?) -> append -> EOS/limit check -> embed.  One block.
+// sample -> (forced?) -> append -> EOS/limit check -> embed.  One block per sequence (blockIdx.x).
 template <typename T>
 __global__ __launch_bounds__(1024) void sample_embed_kernel(T* logits, int vocab, int32_t* st,
                                                             const int32_t* __restrict__ img_ids, int n_img_ids,
                                                             const int32_t* __restrict__ forced, int32_t* gen_ids,
-                                                            const T* __restrict__ embed, T* x, int hidden) {
+                                                            const T* __restrict__ embed, T* x, int hidden,
+                                                            int max_new) {
     __shared__ float sv[16];
     __shared__ int si[16];
+    {
+        const int b = blockIdx.x;
+        logits += (int64_t)b * vocab;
+        st += b * 8;
+        forced += (int64_t)b * max_new;
+        gen_ids += (int64_t)b * max_new;
+        x += (int64_t)b * hidden;
+    }
     if (st[ST_DONE]) return;
     int tok = imgproc_argmax_block<T>(logits, vocab, st[ST_LAST], img_ids, n_img_ids, sv, si);
     const int n = st[ST_NGEN];
@@ -65,13 +78,20 @@ __global__ __launch_bounds__(1024) void sample_embed_kernel(T* logits, int vocab
 }
 
 // final RMSNorm of the single decode row: writes the fixed lm_head input buffer AND the
-// hidden-state ring row (n_gen - 1), then advances kv_len / pos.  One block of 256.
+// hidden-state ring row (n_gen - 1), then advances kv_len / pos.  One block of 256 per sequence.
 template <typename T>
 __global__ __launch_bounds__(256) void final_norm_advance_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                  T* xn, T* hid_rows, int32_t* st, int hidden,
-                                                                 float eps) {
+                                                                 float eps, int max_new) {
     constexpr int V = Tr<T>::kVec;
     __shared__ float red[16];
+    {
+        const int b = blockIdx.x;
+        x += (int64_t)b * hidden;
+        xn += (int64_t)b * hidden;
+        hid_rows += (int64_t)b * max_new * hidden;
+        st += b * 8;
+    }
     if (st[ST_DONE]) return;
     const int npack = hidden / V;
     float ssq = 0.f;
@@ -126,30 +146,37 @@ int rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t co
 
 using namespace ss;
 
+struct SeqGraph {
+    int seq0, nb;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
 struct ss_llama {
     ss_llama_config cfg;
     ss_llama_weights w;
     std::vector<ss_llama_layer_weights> layers;
     int hd;
+    int n_seq;               // sequence slots (independent stories sharing one sweep of the weights)
+    int cur;                 // slot addressed by the single-sequence entry points
     int64_t max_rows;
     size_t esz;
-    // device buffers (carved from the caller's workspace)
-    char *kc, *vc;           // [L][H][cap][hd]
-    int32_t* state;          // [8]
-    int32_t* gen_ids;        // [max_new]
-    int32_t* forced;         // [max_new]
+    // device buffers (carved from the caller's workspace); every per-sequence array is [n_seq][...]
+    char *kc, *vc;           // [n_seq][L][H][cap][hd]
+    int32_t* state;          // [n_seq][8]
+    int32_t* gen_ids;        // [n_seq][max_new]
+    int32_t* forced;         // [n_seq][max_new]
     int32_t* img_ids;        // [n_img_ids]
-    char* hid_rows;          // [max_new][hidden]
-    char* logits;            // [vocab]
-    char *x, *xn, *qkv, *q, *attn, *gu, *hm;  // activations ([max_rows][..]); decode uses row 0
-    float* attn_ws;
+    char* hid_rows;          // [n_seq][max_new][hidden]
+    char* logits;            // [n_seq][vocab]
+    char *x, *xn, *qkv, *q, *attn, *gu, *hm;  // activations ([max_rows][..]); decode uses rows 0..nb-1
+    float* attn_ws;          // [n_seq] split-KV partial slabs
     // host mirrors
-    int64_t kv_len, pos;
+    std::vector<int64_t> kv_len, pos;
     hipStream_t cap_stream;
-    hipGraph_t graph;
-    hipGraphExec_t graph_exec;
-    bool graph_ready;
-    int32_t* pinned;         // 8 ints of pinned host memory for state read-back
+    std::vector<SeqGraph> graphs;
+    int32_t* pinned;         // [2][n_seq][8] ints of pinned host memory: state read-back | state upload
+    size_t seq_kv_bytes() const { return (size_t)cfg.n_layers * cfg.n_heads * cfg.cache_cap * hd * esz; }
 };
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -162,16 +189,15 @@ struct Carver {
 static void carve(ss_llama* h, Carver& c) {
     const ss_llama_config& g = h->cfg;
     const size_t e = h->esz;
-    const size_t H = g.hidden, I = g.inter, R = (size_t)h->max_rows;
-    const size_t kvb = (size_t)g.n_layers * g.n_heads * g.cache_cap * h->hd * e;
-    h->kc = c.take(kvb);
-    h->vc = c.take(kvb);
-    h->state = (int32_t*)c.take(8 * sizeof(int32_t));
-    h->gen_ids = (int32_t*)c.take((size_t)g.max_new * sizeof(int32_t));
-    h->forced = (int32_t*)c.take((size_t)g.max_new * sizeof(int32_t));
+    const size_t H = g.hidden, I = g.inter, R = (size_t)h->max_rows, S = (size_t)h->n_seq;
+    h->kc = c.take(S * h->seq_kv_bytes());
+    h->vc = c.take(S * h->seq_kv_bytes());
+    h->state = (int32_t*)c.take(S * 8 * sizeof(int32_t));
+    h->gen_ids = (int32_t*)c.take(S * (size_t)g.max_new * sizeof(int32_t));
+    h->forced = (int32_t*)c.take(S * (size_t)g.max_new * sizeof(int32_t));
     h->img_ids = (int32_t*)c.take((size_t)(g.n_img_ids > 0 ? g.n_img_ids : 1) * sizeof(int32_t));
-    h->hid_rows = c.take((size_t)g.max_new * H * e);
-    h->logits = c.take((size_t)g.vocab * e);
+    h->hid_rows = c.take(S * (size_t)g.max_new * H * e);
+    h->logits = c.take(S * (size_t)g.vocab * e);
     h->x = c.take(R * H * e);
     h->xn = c.take(R * H * e);
     h->qkv = c.take(R * 3 * H * e);
@@ -179,11 +205,13 @@ static void carve(ss_llama* h, Carver& c) {
     h->attn = c.take(R * H * e);
     h->gu = c.take(R * 2 * I * e);
     h->hm = c.take(R * I * e);
-    h->attn_ws = (float*)c.take(ss_attn_decode_workspace_bytes(g.n_heads, h->hd));
+    h->attn_ws = (float*)c.take(S * ss_attn_decode_workspace_bytes(g.n_heads, h->hd));
 }
 
-// one decode token (sample+forward); eager or under stream capture.  `ev` (optional) receives an
-// event before/after every launch class for profiling.
+static int cfg_n_seq(const ss_llama_config* cfg) { return cfg->n_seq > 0 ? cfg->n_seq : 1; }
+
+// one decode token (sample+forward) for the sequence slots [seq0, seq0+nb); eager or under stream
+// capture.  `prof` (optional) receives an event before/after every launch class for profiling.
 struct ProfSink {
     std::vector<hipEvent_t> ev;
     std::vector<int> cls;
@@ -197,72 +225,130 @@ struct ProfSink {
     }
 };
 
-static int decode_token(ss_llama* h, hipStream_t s, ProfSink* prof) {
+static int decode_token(ss_llama* h, hipStream_t s, ProfSink* prof, int seq0, int nb) {
     const ss_llama_config& g = h->cfg;
     const int dt = g.dtype;
     const int H = g.hidden, I = g.inter, hd = h->hd;
     const size_t e = h->esz;
-    const int32_t* done = h->state + ST_DONE;
+    int32_t* st = h->state + (size_t)seq0 * 8;
+    const int32_t* done = st + ST_DONE;
     const size_t plane = (size_t)g.n_heads * g.cache_cap * hd * e;
+    const size_t seq_kv = h->seq_kv_bytes();
+    const int64_t cache_stride = (int64_t)(seq_kv / e);
+    char* logits = h->logits + (size_t)seq0 * g.vocab * e;
+    int32_t* forced = h->forced + (size_t)seq0 * g.max_new;
+    int32_t* gen_ids = h->gen_ids + (size_t)seq0 * g.max_new;
+    char* hid_rows = h->hid_rows + (size_t)seq0 * g.max_new * H * e;
+    float* attn_ws = (float*)((char*)h->attn_ws + (size_t)seq0 * ss_attn_decode_workspace_bytes(g.n_heads, hd));
 #define MARK(c) do { if (prof) prof->mark(c); } while (0)
+#define SAMPLE(T)                                                                                                  \
+    hipLaunchKernelGGL(sample_embed_kernel<T>, dim3((unsigned)nb), dim3(1024), 0, s, (T*)logits, g.vocab, st,        \
+                       h->img_ids, g.n_img_ids, forced, gen_ids, (const T*)h->w.embed, (T*)h->x, H, g.max_new)
+#define FINAL(T)                                                                                                   \
+    hipLaunchKernelGGL(final_norm_advance_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, (const T*)h->x,            \
+                       (const T*)h->w.final_norm, (T*)h->xn, (T*)hid_rows, st, H, g.rms_eps, g.max_new)
     MARK(-1);
-    if (dt == SS_BF16)
-        hipLaunchKernelGGL(sample_embed_kernel<bf16_t>, dim3(1), dim3(1024), 0, s, (bf16_t*)h->logits, g.vocab, h->state,
-                           h->img_ids, g.n_img_ids, h->forced, h->gen_ids, (const bf16_t*)h->w.embed, (bf16_t*)h->x, H);
-    else if (dt == SS_F32)
-        hipLaunchKernelGGL(sample_embed_kernel<float>, dim3(1), dim3(1024), 0, s, (float*)h->logits, g.vocab, h->state,
-                           h->img_ids, g.n_img_ids, h->forced, h->gen_ids, (const float*)h->w.embed, (float*)h->x, H);
-    else
-        hipLaunchKernelGGL(sample_embed_kernel<f16_t>, dim3(1), dim3(1024), 0, s, (f16_t*)h->logits, g.vocab, h->state,
-                           h->img_ids, g.n_img_ids, h->forced, h->gen_ids, (const f16_t*)h->w.embed, (f16_t*)h->x, H);
+    if (dt == SS_BF16) SAMPLE(bf16_t);
+    else if (dt == SS_F32) SAMPLE(float);
+    else SAMPLE(f16_t);
     SS_LAUNCH_CHECK("sample_embed");
     MARK(3);
     for (int l = 0; l < g.n_layers; ++l) {
         const ss_llama_layer_weights& L = h->layers[l];
-        char* kc = h->kc + (size_t)l * plane;
-        char* vc = h->vc + (size_t)l * plane;
+        char* kc = h->kc + (size_t)seq0 * seq_kv + (size_t)l * plane;
+        char* vc = h->vc + (size_t)seq0 * seq_kv + (size_t)l * plane;
         int rc;
         MARK(-1);
-        rc = gemv_dev(L.wqkv, h->x, h->qkv, 3 * H, H, L.ln1, g.rms_eps, nullptr, nullptr, SS_EPI_NONE, done, dt, s);
+        rc = gemv_batched_dev(L.wqkv, h->x, h->qkv, 3 * H, H, L.ln1, g.rms_eps, nullptr, nullptr, SS_EPI_NONE, done, 8,
+                              nb, H, 3 * H, 0, dt, s);
         if (rc) return rc;
         MARK(0);
         // RoPE(q,k) + KV append + split-KV attention in one kernel (+ the split merge)
-        rc = attn_decode_fused_dev(h->qkv, kc, vc, h->w.rope_cos, h->w.rope_sin, h->attn, h->attn_ws,
-                                   h->state + ST_KV_LEN, h->state + ST_POS, done, g.n_heads, hd, g.cache_cap, dt, s);
+        rc = attn_decode_fused_dev(h->qkv, kc, vc, h->w.rope_cos, h->w.rope_sin, h->attn, attn_ws, st + ST_KV_LEN,
+                                   st + ST_POS, done, g.n_heads, hd, g.cache_cap, nb, 8, cache_stride, dt, s);
         if (rc) return rc;
         MARK(1);
-        rc = gemv_dev(L.wo, h->attn, h->xn, H, H, nullptr, 0.f, nullptr, h->x, SS_EPI_RESIDUAL, done, dt, s);
+        rc = gemv_batched_dev(L.wo, h->attn, h->xn, H, H, nullptr, 0.f, nullptr, h->x, SS_EPI_RESIDUAL, done, 8, nb, H,
+                              H, H, dt, s);
         if (rc) return rc;
         MARK(0);
-        rc = gemv_dev(L.wgu, h->xn, h->hm, I, H, L.ln2, g.rms_eps, nullptr, nullptr, SS_EPI_SILU_MUL, done, dt, s);
+        rc = gemv_batched_dev(L.wgu, h->xn, h->hm, I, H, L.ln2, g.rms_eps, nullptr, nullptr, SS_EPI_SILU_MUL, done, 8,
+                              nb, H, I, 0, dt, s);
         if (rc) return rc;
         MARK(0);
-        rc = gemv_dev(L.wdown, h->hm, h->x, H, I, nullptr, 0.f, nullptr, h->xn, SS_EPI_RESIDUAL, done, dt, s);
+        rc = gemv_batched_dev(L.wdown, h->hm, h->x, H, I, nullptr, 0.f, nullptr, h->xn, SS_EPI_RESIDUAL, done, 8, nb, I,
+                              H, H, dt, s);
         if (rc) return rc;
         MARK(2);
     }
-    if (dt == SS_BF16)
-        hipLaunchKernelGGL(final_norm_advance_kernel<bf16_t>, dim3(1), dim3(256), 0, s, (const bf16_t*)h->x,
-                           (const bf16_t*)h->w.final_norm, (bf16_t*)h->xn, (bf16_t*)h->hid_rows, h->state, H, g.rms_eps);
-    else if (dt == SS_F32)
-        hipLaunchKernelGGL(final_norm_advance_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)h->x,
-                           (const float*)h->w.final_norm, (float*)h->xn, (float*)h->hid_rows, h->state, H, g.rms_eps);
-    else
-        hipLaunchKernelGGL(final_norm_advance_kernel<f16_t>, dim3(1), dim3(256), 0, s, (const f16_t*)h->x,
-                           (const f16_t*)h->w.final_norm, (f16_t*)h->xn, (f16_t*)h->hid_rows, h->state, H, g.rms_eps);
+    if (dt == SS_BF16) FINAL(bf16_t);
+    else if (dt == SS_F32) FINAL(float);
+    else FINAL(f16_t);
     SS_LAUNCH_CHECK("final_norm_advance");
     MARK(3);
-    int rc = gemv_dev(h->w.lm_head, h->xn, h->logits, g.vocab, H, nullptr, 0.f, nullptr, nullptr, SS_EPI_NONE, done,
-                      dt, s);
+    int rc = gemv_batched_dev(h->w.lm_head, h->xn, logits, g.vocab, H, nullptr, 0.f, nullptr, nullptr, SS_EPI_NONE, done,
+                              8, nb, H, g.vocab, 0, dt, s);
     if (rc) return rc;
     MARK(0);
 #undef MARK
+#undef SAMPLE
+#undef FINAL
     return SS_OK;
 }
 
 static int read_state(ss_llama* h, hipStream_t s) {
-    SS_HIP(hipMemcpyAsync(h->pinned, h->state, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SS_HIP(hipMemcpyAsync(h->pinned, h->state, (size_t)h->n_seq * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SS_HIP(hipStreamSynchronize(s));
+    return SS_OK;
+}
+
+// captured decode token for slots [seq0, seq0+nb), built on first use
+static int graph_for(ss_llama* h, int seq0, int nb, hipGraphExec_t* out) {
+    for (const SeqGraph& sg : h->graphs)
+        if (sg.seq0 == seq0 && sg.nb == nb) { *out = sg.exec; return SS_OK; }
+    SeqGraph sg;
+    sg.seq0 = seq0; sg.nb = nb; sg.graph = nullptr; sg.exec = nullptr;
+    SS_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = decode_token(h, h->cap_stream, nullptr, seq0, nb);
+    hipError_t ce = hipStreamEndCapture(h->cap_stream, &sg.graph);
+    if (rc) return rc;
+    SS_HIP(ce);
+    SS_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+    h->graphs.push_back(sg);
+    *out = sg.exec;
+    return SS_OK;
+}
+
+// shared driver of ss_llama_generate / ss_llama_generate_batch: the state words of slots
+// [seq0, seq0+nb) have been staged in h->pinned[upload area]; replays the decode graph until every
+// slot reports done or `eff_limit` tokens were launched.
+static int run_decode(ss_llama* h, int seq0, int nb, int64_t eff_limit, hipStream_t s) {
+    int32_t* init = h->pinned + (size_t)h->n_seq * 8;
+    SS_HIP(hipMemcpyAsync(h->state + (size_t)seq0 * 8, init + (size_t)seq0 * 8, (size_t)nb * 8 * sizeof(int32_t),
+                          hipMemcpyHostToDevice, s));
+    const bool use_graph = tuning_get("llama_graph", 1) != 0;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) { int rc = graph_for(h, seq0, nb, &exec); if (rc) return rc; }
+    const int chunk = tuning_get("llama_done_poll", 8);
+    int64_t launched = 0;
+    while (launched < eff_limit) {
+        const int64_t n = (eff_limit - launched) < chunk ? (eff_limit - launched) : chunk;
+        for (int64_t i = 0; i < n; ++i) {
+            if (use_graph) SS_HIP(hipGraphLaunch(exec, s));
+            else { int rc = decode_token(h, s, nullptr, seq0, nb); if (rc) return rc; }
+        }
+        launched += n;
+        int rc = read_state(h, s);
+        if (rc) return rc;
+        bool all = true;
+        for (int b = seq0; b < seq0 + nb; ++b) all = all && h->pinned[b * 8 + ST_DONE];
+        if (all) break;
+    }
+    if (launched == 0) { int rc = read_state(h, s); if (rc) return rc; }
+    for (int b = seq0; b < seq0 + nb; ++b) {
+        h->kv_len[b] = h->pinned[b * 8 + ST_KV_LEN];
+        h->pos[b] = h->pinned[b * 8 + ST_POS];
+    }
     return SS_OK;
 }
 
@@ -273,7 +359,8 @@ size_t ss_llama_workspace_bytes(const ss_llama_config* cfg, int64_t max_prefill_
     ss_llama tmp;
     tmp.cfg = *cfg;
     tmp.hd = cfg->hidden / cfg->n_heads;
-    tmp.max_rows = max_prefill_rows < 1 ? 1 : max_prefill_rows;
+    tmp.n_seq = cfg_n_seq(cfg);
+    tmp.max_rows = max_prefill_rows < tmp.n_seq ? tmp.n_seq : max_prefill_rows;
     tmp.esz = dtype_size(cfg->dtype);
     Carver c{nullptr, 0, 0};
     carve(&tmp, c);
@@ -285,6 +372,7 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
     SS_REQUIRE(cfg && w && workspace && out, "llama_create: null argument");
     SS_REQUIRE(cfg->hidden % cfg->n_heads == 0, "llama_create: hidden %% n_heads != 0");
     SS_REQUIRE(cfg->n_img_ids <= 1024 && cfg->max_new > 0 && cfg->cache_cap > 0, "llama_create: bad config");
+    SS_REQUIRE(cfg->n_seq >= 0 && cfg->n_seq <= 4, "llama_create: n_seq=%d unsupported (1..4)", cfg->n_seq);
     int32_t info[4];
     int rc = ss_device_info(info);
     if (rc) return rc;
@@ -295,7 +383,9 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
     h->layers.assign(w->layers, w->layers + cfg->n_layers);
     h->w.layers = h->layers.data();
     h->hd = cfg->hidden / cfg->n_heads;
-    h->max_rows = max_prefill_rows < 1 ? 1 : max_prefill_rows;
+    h->n_seq = cfg_n_seq(cfg);
+    h->cur = 0;
+    h->max_rows = max_prefill_rows < h->n_seq ? h->n_seq : max_prefill_rows;
     h->esz = dtype_size(cfg->dtype);
     const size_t base = (size_t)workspace;
     const size_t skew = align_up(base) - base;
@@ -306,11 +396,12 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
         delete h;
         return SS_ENOMEM;
     }
-    h->kv_len = 0; h->pos = 0;
-    h->graph_ready = false; h->graph = nullptr; h->graph_exec = nullptr;
+    h->kv_len.assign(h->n_seq, 0);
+    h->pos.assign(h->n_seq, 0);
     hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->pinned, 128, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemset(h->state, 0, 8 * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&h->pinned, (size_t)h->n_seq * 16 * sizeof(int32_t) + 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)h->n_seq * 8 * sizeof(int32_t));
     if (e == hipSuccess && cfg->n_img_ids > 0)
         e = hipMemcpy(h->img_ids, host_img_ids, cfg->n_img_ids * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = check_hip(e, "llama_create"); delete h; return rc; }
@@ -320,22 +411,32 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
 
 void ss_llama_destroy(ss_llama* h) {
     if (!h) return;
-    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) hipGraphDestroy(h->graph);
+    for (SeqGraph& sg : h->graphs) {
+        if (sg.exec) hipGraphExecDestroy(sg.exec);
+        if (sg.graph) hipGraphDestroy(sg.graph);
+    }
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     if (h->pinned) hipHostFree(h->pinned);
     delete h;
 }
 
+int ss_llama_select(ss_llama* h, int32_t seq) {
+    SS_REQUIRE(h && seq >= 0 && seq < h->n_seq, "llama_select: sequence slot %d out of range", (int)seq);
+    h->cur = seq;
+    return SS_OK;
+}
+
 void* ss_llama_buffer(ss_llama* h, int which) {
     if (!h) return nullptr;
+    const ss_llama_config& g = h->cfg;
+    const size_t q = (size_t)h->cur;
     switch (which) {
-        case 0: return h->kc;
-        case 1: return h->vc;
-        case 2: return h->gen_ids;
-        case 3: return h->hid_rows;
-        case 4: return h->logits;
-        case 5: return h->state;
+        case 0: return h->kc + q * h->seq_kv_bytes();
+        case 1: return h->vc + q * h->seq_kv_bytes();
+        case 2: return h->gen_ids + q * g.max_new;
+        case 3: return h->hid_rows + q * (size_t)g.max_new * g.hidden * h->esz;
+        case 4: return h->logits + q * (size_t)g.vocab * h->esz;
+        case 5: return h->state + q * 8;
         default: return nullptr;
     }
 }
@@ -343,23 +444,23 @@ void* ss_llama_buffer(ss_llama* h, int which) {
 int ss_llama_set_lengths(ss_llama* h, int64_t kv_len, int64_t pos, void* stream) {
     SS_REQUIRE(h && kv_len >= 0 && kv_len <= h->cfg.cache_cap && pos >= 0 && pos < h->cfg.max_pos,
                "llama_set_lengths: out of range (kv_len=%lld pos=%lld)", (long long)kv_len, (long long)pos);
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->state, (int)ST_KV_LEN,
-                       (int)kv_len, (int)ST_POS, (int)pos);
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->state + (size_t)h->cur * 8,
+                       (int)ST_KV_LEN, (int)kv_len, (int)ST_POS, (int)pos);
     SS_LAUNCH_CHECK("set_state");
-    h->kv_len = kv_len;
-    h->pos = pos;
+    h->kv_len[h->cur] = kv_len;
+    h->pos[h->cur] = pos;
     return SS_OK;
 }
 
 int ss_llama_get_lengths(ss_llama* h, int64_t* kv_len, int64_t* pos) {
     SS_REQUIRE(h, "llama_get_lengths: null handle");
-    if (kv_len) *kv_len = h->kv_len;
-    if (pos) *pos = h->pos;
+    if (kv_len) *kv_len = h->kv_len[h->cur];
+    if (pos) *pos = h->pos[h->cur];
     return SS_OK;
 }
 
 int ss_llama_kv_gather(ss_llama* h, const int32_t* keep_idx_dev, int64_t n_keep, void* stream) {
-    SS_REQUIRE(h && keep_idx_dev && n_keep >= 0 && n_keep <= h->kv_len, "llama_kv_gather: bad arguments");
+    SS_REQUIRE(h && keep_idx_dev && n_keep >= 0 && n_keep <= h->kv_len[h->cur], "llama_kv_gather: bad arguments");
     const ss_llama_config& g = h->cfg;
     const size_t e = h->esz;
     // scratch = qkv activation buffer: [max_rows][3*hidden] elements >= n_heads * n_keep * hd = n_keep * hidden
@@ -367,13 +468,15 @@ int ss_llama_kv_gather(ss_llama* h, const int32_t* keep_idx_dev, int64_t n_keep,
                (long long)n_keep, (long long)h->max_rows);
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)g.n_heads * g.cache_cap * h->hd * e;
+    char* kbase = h->kc + (size_t)h->cur * h->seq_kv_bytes();
+    char* vbase = h->vc + (size_t)h->cur * h->seq_kv_bytes();
     const int V = g.dtype == SS_F32 ? 4 : 8;
     dim3 grid((unsigned)cdiv(n_keep * (h->hd / V), 256) > 0 ? (unsigned)cdiv(n_keep * (h->hd / V), 256) : 1,
               (unsigned)g.n_heads);
     if (n_keep > 0) {
         for (int l = 0; l < g.n_layers; ++l) {
             for (int kv = 0; kv < 2; ++kv) {
-                char* plane_p = (kv ? h->vc : h->kc) + (size_t)l * plane;
+                char* plane_p = (kv ? vbase : kbase) + (size_t)l * plane;
 #define GATHER(T)                                                                                                  \
     hipLaunchKernelGGL(kv_gather_kernel<T>, grid, dim3(256), 0, s, (const T*)plane_p, (T*)h->qkv, keep_idx_dev,     \
                        (int)n_keep, g.cache_cap, h->hd, (int)n_keep);                                               \
@@ -387,7 +490,7 @@ int ss_llama_kv_gather(ss_llama* h, const int32_t* keep_idx_dev, int64_t n_keep,
             }
         }
     }
-    return ss_llama_set_lengths(h, n_keep, h->pos, stream);
+    return ss_llama_set_lengths(h, n_keep, h->pos[h->cur], stream);
 }
 
 int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* pos_ids, void* hidden_out,
@@ -395,9 +498,10 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
     SS_REQUIRE(h && embeds && M > 0, "llama_prefill: bad arguments");
     SS_REQUIRE(M <= h->max_rows, "llama_prefill: M=%lld exceeds max_prefill_rows=%lld", (long long)M,
                (long long)h->max_rows);
-    SS_REQUIRE(h->kv_len + M <= h->cfg.cache_cap, "llama_prefill: KV cache overflow (%lld + %lld > %d)",
-               (long long)h->kv_len, (long long)M, h->cfg.cache_cap);
-    SS_REQUIRE(pos_ids || h->pos + M <= h->cfg.max_pos, "llama_prefill: position overflow");
+    const int64_t cur_kv = h->kv_len[h->cur], cur_pos = h->pos[h->cur];
+    SS_REQUIRE(cur_kv + M <= h->cfg.cache_cap, "llama_prefill: KV cache overflow (%lld + %lld > %d)",
+               (long long)cur_kv, (long long)M, h->cfg.cache_cap);
+    SS_REQUIRE(pos_ids || cur_pos + M <= h->cfg.max_pos, "llama_prefill: position overflow");
     const ss_llama_config& g = h->cfg;
     hipStream_t s = (hipStream_t)stream;
     const int dt = g.dtype;
@@ -405,17 +509,19 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
     const int hd = h->hd;
     const size_t e = h->esz;
     const size_t plane = (size_t)g.n_heads * g.cache_cap * hd * e;
-    const int64_t kv0 = h->kv_len, kv1 = h->kv_len + M;
+    char* kbase = h->kc + (size_t)h->cur * h->seq_kv_bytes();
+    char* vbase = h->vc + (size_t)h->cur * h->seq_kv_bytes();
+    const int64_t kv0 = cur_kv, kv1 = cur_kv + M;
     int rc;
     SS_HIP(hipMemcpyAsync(h->x, embeds, (size_t)M * H * e, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < g.n_layers; ++l) {
         const ss_llama_layer_weights& L = h->layers[l];
-        char* kc = h->kc + (size_t)l * plane;
-        char* vc = h->vc + (size_t)l * plane;
+        char* kc = kbase + (size_t)l * plane;
+        char* vc = vbase + (size_t)l * plane;
         if ((rc = rmsnorm_rows(h->x, L.ln1, h->xn, M, H, g.rms_eps, dt, s))) return rc;
         if ((rc = gemm_dev(h->xn, L.wqkv, h->qkv, M, 3 * H, H, H, H, 3 * H, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
             return rc;
-        if ((rc = ss_rope_kv_append(h->qkv, h->q, kc, vc, h->w.rope_cos, h->w.rope_sin, pos_ids, h->pos, M, g.n_heads,
+        if ((rc = ss_rope_kv_append(h->qkv, h->q, kc, vc, h->w.rope_cos, h->w.rope_sin, pos_ids, cur_pos, M, g.n_heads,
                                     hd, kv0, g.cache_cap, dt, stream)))
             return rc;
         if ((rc = ss_attention(h->q, kc, vc, h->attn, 1, g.n_heads, M, kv1, hd, 0, hd, H, 0, (int64_t)g.cache_cap * hd,
@@ -432,11 +538,27 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
     void* hid = hidden_out ? hidden_out : (void*)h->xn;
     if ((rc = rmsnorm_rows(h->x, h->w.final_norm, hid, M, H, g.rms_eps, dt, s))) return rc;
     const char* last = (const char*)hid + (size_t)(M - 1) * H * e;
-    if ((rc = gemv_dev(h->w.lm_head, last, h->logits, g.vocab, H, nullptr, 0.f, nullptr, nullptr, SS_EPI_NONE, nullptr,
+    char* logits = h->logits + (size_t)h->cur * g.vocab * e;
+    if ((rc = gemv_dev(h->w.lm_head, last, logits, g.vocab, H, nullptr, 0.f, nullptr, nullptr, SS_EPI_NONE, nullptr,
                        dt, s)))
         return rc;
-    const int64_t new_pos = pos_ids ? h->pos : h->pos + M;  // explicit pos_ids: caller sets pos afterwards
+    const int64_t new_pos = pos_ids ? cur_pos : cur_pos + M;  // explicit pos_ids: caller sets pos afterwards
     return ss_llama_set_lengths(h, kv1, new_pos, stream);
+}
+
+// stage one slot's initial decode state in the pinned upload area; returns the launch bound
+static int64_t stage_seq(ss_llama* h, int b, int64_t n_steps, int32_t last_id, const int32_t* forced, int64_t n_forced,
+                         bool active) {
+    const ss_llama_config& g = h->cfg;
+    const int64_t limit = n_steps < g.max_new ? n_steps : g.max_new;
+    int64_t eff = limit;
+    for (int64_t i = 0; i < n_forced && i < eff; ++i)
+        if (forced[i] == g.eos_id) { eff = i + 1; break; }  // the host already knows where it stops
+    int32_t* init = h->pinned + (size_t)h->n_seq * 8 + (size_t)b * 8;
+    init[ST_KV_LEN] = (int32_t)h->kv_len[b]; init[ST_POS] = (int32_t)h->pos[b]; init[ST_NGEN] = 0;
+    init[ST_DONE] = active ? 0 : 1; init[ST_LAST] = last_id; init[ST_NFORCED] = (int32_t)n_forced;
+    init[ST_LIMIT] = (int32_t)limit; init[ST_EOS] = g.eos_id;
+    return active ? eff : 0;
 }
 
 int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, const int32_t* host_forced,
@@ -444,47 +566,48 @@ int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, cons
     SS_REQUIRE(h && n_steps > 0, "llama_generate: bad arguments");
     const ss_llama_config& g = h->cfg;
     hipStream_t s = (hipStream_t)stream;
+    const int q = h->cur;
     const int64_t limit = n_steps < g.max_new ? n_steps : g.max_new;
     SS_REQUIRE(n_forced >= 0 && n_forced <= g.max_new, "llama_generate: n_forced out of range");
-    SS_REQUIRE(h->kv_len + limit <= g.cache_cap, "llama_generate: KV cache overflow (%lld + %lld > %d)",
-               (long long)h->kv_len, (long long)limit, g.cache_cap);
-    int64_t eff_limit = limit;
-    for (int64_t i = 0; i < n_forced && i < eff_limit; ++i)
-        if (host_forced[i] == g.eos_id) { eff_limit = i + 1; break; }  // the host already knows where it stops
+    SS_REQUIRE(h->kv_len[q] + limit <= g.cache_cap, "llama_generate: KV cache overflow (%lld + %lld > %d)",
+               (long long)h->kv_len[q], (long long)limit, g.cache_cap);
     if (n_forced > 0)
-        SS_HIP(hipMemcpyAsync(h->forced, host_forced, (size_t)n_forced * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    // state upload staged in pinned memory (words 8..15); consumed before this call returns (read_state syncs)
-    int32_t* init = h->pinned + 8;
-    init[ST_KV_LEN] = (int32_t)h->kv_len; init[ST_POS] = (int32_t)h->pos; init[ST_NGEN] = 0; init[ST_DONE] = 0;
-    init[ST_LAST] = last_prompt_id; init[ST_NFORCED] = (int32_t)n_forced; init[ST_LIMIT] = (int32_t)limit;
-    init[ST_EOS] = g.eos_id;
-    SS_HIP(hipMemcpyAsync(h->state, init, 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    const bool use_graph = tuning_get("llama_graph", 1) != 0;
-    if (use_graph && !h->graph_ready) {
-        SS_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = decode_token(h, h->cap_stream, nullptr);
-        hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
-        if (rc) return rc;
-        SS_HIP(ce);
-        SS_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-        h->graph_ready = true;
+        SS_HIP(hipMemcpyAsync(h->forced + (size_t)q * g.max_new, host_forced, (size_t)n_forced * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
+    // state upload staged in pinned memory; consumed before this call returns (read_state syncs)
+    const int64_t eff_limit = stage_seq(h, q, n_steps, last_prompt_id, host_forced, n_forced, true);
+    int rc = run_decode(h, q, 1, eff_limit, s);
+    if (rc) return rc;
+    if (host_n_generated) *host_n_generated = h->pinned[q * 8 + ST_NGEN];
+    return SS_OK;
+}
+
+int ss_llama_generate_batch(ss_llama* h, int64_t n_steps, const int32_t* last_prompt_ids, const int32_t* host_forced,
+                            int64_t forced_ld, const int64_t* n_forced, const int32_t* active,
+                            int64_t* host_n_generated, void* stream) {
+    SS_REQUIRE(h && n_steps > 0 && last_prompt_ids, "llama_generate_batch: bad arguments");
+    const ss_llama_config& g = h->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t limit = n_steps < g.max_new ? n_steps : g.max_new;
+    int64_t eff_limit = 0;
+    for (int b = 0; b < h->n_seq; ++b) {
+        const bool on = !active || active[b];
+        const int64_t nf = (n_forced && host_forced) ? n_forced[b] : 0;
+        SS_REQUIRE(nf >= 0 && nf <= g.max_new && nf <= forced_ld, "llama_generate_batch: n_forced[%d] out of range", b);
+        SS_REQUIRE(!on || h->kv_len[b] + limit <= g.cache_cap,
+                   "llama_generate_batch: KV cache overflow in slot %d (%lld + %lld > %d)", b, (long long)h->kv_len[b],
+                   (long long)limit, g.cache_cap);
+        const int32_t* f = host_forced ? host_forced + (size_t)b * forced_ld : nullptr;
+        if (on && nf > 0)
+            SS_HIP(hipMemcpyAsync(h->forced + (size_t)b * g.max_new, f, (size_t)nf * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, s));
+        const int64_t eff = stage_seq(h, b, n_steps, last_prompt_ids[b], f, on ? nf : 0, on);
+        if (eff > eff_limit) eff_limit = eff;
     }
-    const int chunk = tuning_get("llama_done_poll", 8);
-    int64_t launched = 0;
-    while (launched < eff_limit) {
-        const int64_t n = (eff_limit - launched) < chunk ? (eff_limit - launched) : chunk;
-        for (int64_t i = 0; i < n; ++i) {
-            if (use_graph) SS_HIP(hipGraphLaunch(h->graph_exec, s));
-            else { int rc = decode_token(h, s, nullptr); if (rc) return rc; }
-        }
-        launched += n;
-        int rc = read_state(h, s);
-        if (rc) return rc;
-        if (h->pinned[ST_DONE]) break;
-    }
-    h->kv_len = h->pinned[ST_KV_LEN];
-    h->pos = h->pinned[ST_POS];
-    if (host_n_generated) *host_n_generated = h->pinned[ST_NGEN];
+    int rc = run_decode(h, 0, h->n_seq, eff_limit, s);
+    if (rc) return rc;
+    if (host_n_generated)
+        for (int b = 0; b < h->n_seq; ++b) host_n_generated[b] = h->pinned[b * 8 + ST_NGEN];
     return SS_OK;
 }
 
@@ -492,17 +615,20 @@ int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], doub
     SS_REQUIRE(h && n_tokens > 0 && out_ms && out_bytes, "llama_profile_decode: bad arguments");
     const ss_llama_config& g = h->cfg;
     hipStream_t s = (hipStream_t)stream;
-    SS_REQUIRE(h->kv_len + n_tokens + 1 <= g.cache_cap, "llama_profile_decode: KV cache too full");
-    int32_t* init = h->pinned + 8;
-    init[ST_KV_LEN] = (int32_t)h->kv_len; init[ST_POS] = (int32_t)h->pos; init[ST_NGEN] = 0; init[ST_DONE] = 0;
-    init[ST_LAST] = 0; init[ST_NFORCED] = 0; init[ST_LIMIT] = g.max_new; init[ST_EOS] = -1;
-    SS_HIP(hipMemcpyAsync(h->state, init, 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    int32_t* init = h->pinned + (size_t)h->n_seq * 8;
+    for (int b = 0; b < h->n_seq; ++b) {
+        SS_REQUIRE(h->kv_len[b] + n_tokens + 1 <= g.cache_cap, "llama_profile_decode: KV cache too full (slot %d)", b);
+        int32_t* st = init + b * 8;
+        st[ST_KV_LEN] = (int32_t)h->kv_len[b]; st[ST_POS] = (int32_t)h->pos[b]; st[ST_NGEN] = 0; st[ST_DONE] = 0;
+        st[ST_LAST] = 0; st[ST_NFORCED] = 0; st[ST_LIMIT] = g.max_new; st[ST_EOS] = -1;
+    }
+    SS_HIP(hipMemcpyAsync(h->state, init, (size_t)h->n_seq * 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 8; ++i) out_ms[i] = 0.f;
     double cnt[4] = {0, 0, 0, 0};
     for (int64_t t = 0; t < n_tokens && t < g.max_new - 1; ++t) {
         ProfSink p;
         p.s = s;
-        int rc = decode_token(h, s, &p);
+        int rc = decode_token(h, s, &p, 0, h->n_seq);
         hipError_t e = hipStreamSynchronize(s);
         if (!rc && e == hipSuccess) {
             for (size_t i = 1; i < p.ev.size(); ++i) {
@@ -527,8 +653,10 @@ int ss_llama_profile_decode(ss_llama* h, int64_t n_tokens, float out_ms[8], doub
     out_bytes[3] = cnt[2] / (double)n_tokens;
     int rc = read_state(h, s);
     if (rc) return rc;
-    h->kv_len = h->pinned[ST_KV_LEN];
-    h->pos = h->pinned[ST_POS];
+    for (int b = 0; b < h->n_seq; ++b) {
+        h->kv_len[b] = h->pinned[b * 8 + ST_KV_LEN];
+        h->pos[b] = h->pinned[b * 8 + ST_POS];
+    }
     return SS_OK;
 }
 

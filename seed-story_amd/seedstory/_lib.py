@@ -23,7 +23,7 @@ class SSError(RuntimeError):
 class LlamaConfig(C.Structure):
     _fields_ = [("hidden", i32), ("n_heads", i32), ("n_layers", i32), ("inter", i32), ("vocab", i32),
                 ("max_pos", i32), ("rms_eps", f32), ("dtype", i32), ("cache_cap", i32), ("max_new", i32),
-                ("n_img_ids", i32), ("eos_id", i32)]
+                ("n_img_ids", i32), ("eos_id", i32), ("n_seq", i32)]
 
 
 class LlamaLayerWeights(C.Structure):
@@ -73,17 +73,20 @@ PROTOTYPES = {
     "ss_attn_decode": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "ss_gemm": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, C.c_int, vp]),
     "ss_gemv": (C.c_int, [vp, vp, vp, i64, i64, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
+    "ss_gemv_batched": (C.c_int, [vp, vp, vp, i64, i64, i64, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
     "ss_imgproc_argmax": (C.c_int, [vp, i64, vp, vp, i64, vp, C.c_int, vp]),
     "ss_llama_workspace_bytes": (sz, [C.POINTER(LlamaConfig), i64]),
     "ss_llama_create": (C.c_int, [C.POINTER(LlamaConfig), C.POINTER(LlamaWeights), vp, sz, i64, i32p,
                                   C.POINTER(vp)]),
     "ss_llama_destroy": (None, [vp]),
+    "ss_llama_select": (C.c_int, [vp, i32]),
     "ss_llama_buffer": (vp, [vp, C.c_int]),
     "ss_llama_set_lengths": (C.c_int, [vp, i64, i64, vp]),
     "ss_llama_get_lengths": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "ss_llama_kv_gather": (C.c_int, [vp, vp, i64, vp]),
     "ss_llama_prefill": (C.c_int, [vp, vp, i64, vp, vp, vp]),
     "ss_llama_generate": (C.c_int, [vp, i64, i32, i32p, i64, C.POINTER(i64), vp]),
+    "ss_llama_generate_batch": (C.c_int, [vp, i64, i32p, i32p, i64, C.POINTER(i64), i32p, C.POINTER(i64), vp]),
     "ss_llama_profile_decode": (C.c_int, [vp, i64, C.POINTER(f32), C.POINTER(C.c_double), vp]),
     "ss_resampler_workspace_bytes": (sz, [C.POINTER(ResamplerWeights), i64, C.c_int]),
     "ss_resampler_forward": (C.c_int, [C.POINTER(ResamplerWeights), vp, vp, i64, vp, sz, C.c_int, vp]),

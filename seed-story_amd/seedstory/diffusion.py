@@ -605,26 +605,30 @@ class StableDiffusionXLPipeline:
                  output_type="pil", **kw):
         dev, dt = prompt_embeds.device, prompt_embeds.dtype
         lh, lw = height // 8, width // 8
+        B = prompt_embeds.shape[0]           # images rendered together (UNet batch 2B: [B uncond; B cond])
         self.unet._ctx_key = None            # new conditioning: recompute the cached cross-attention K/V
         self.scheduler.set_timesteps(num_inference_steps)
         sig, ts = self.scheduler.sigmas, self.scheduler.timesteps
         if latents is None:
-            latents = torch.randn((1, 4, lh, lw), generator=generator, device=dev, dtype=dt)
+            latents = torch.randn((B, 4, lh, lw), generator=generator, device=dev, dtype=dt)
+        assert latents.shape[0] == B
         x = (latents.to(device=dev, dtype=dt) * self.scheduler.init_noise_sigma).contiguous()
-        time_ids = torch.tensor([[height, width, 0, 0, height, width]] * 2, dtype=torch.float32)
+        time_ids = torch.tensor([[height, width, 0, 0, height, width]] * (2 * B), dtype=torch.float32)
         ctx = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).contiguous()
         pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0).contiguous()
         cond = {"text_embeds": pooled, "time_ids": time_ids}
         for i in range(num_inference_steps):
-            xin = ops.euler_scale_dup(x, float(sig[i])).view(2, 4, lh, lw)   # [uncond; cond] batch, x/sqrt(s^2+1)
+            xin = ops.euler_scale_dup(x, float(sig[i])).view(2 * B, 4, lh, lw)   # [uncond; cond] batch, x/sqrt(s^2+1)
             eps = self.unet(xin, float(ts[i]), ctx, added_cond_kwargs=cond, return_dict=False)[0]
             ops.euler_cfg_step_(x, eps.contiguous(), guidance_scale, float(sig[i]), float(sig[i + 1]))
         if output_type == "latent":
             return _PipeOut(x)
         # latents / scaling_factor is folded into the 1x1 post_quant_conv weights (linear, exact in fp32)
-        img, H, W = self.vae.decode_nhwc(x.view(1, 4, lh, lw), prescale=1.0 / self.vae.config.scaling_factor)
-        u8 = ops.image_to_u8(img, H * W).view(H, W, 3)
+        imgs = []
+        for b in range(B):                   # one image at a time: the 1024^2 decoder activations are 0.5 GB each
+            img, H, W = self.vae.decode_nhwc(x[b:b + 1].contiguous(), prescale=1.0 / self.vae.config.scaling_factor)
+            imgs.append(ops.image_to_u8(img, H * W).view(H, W, 3))
         if output_type == "pt":
-            return _PipeOut(u8)
+            return _PipeOut(imgs[0] if B == 1 else torch.stack(imgs))
         from PIL import Image
-        return _PipeOut([Image.fromarray(u8.cpu().numpy())])
+        return _PipeOut([Image.fromarray(u8.cpu().numpy()) for u8 in imgs])

@@ -39,7 +39,8 @@ def _merged(sd, name, dtype, device, lora_scaling):
 class LlamaEngine:
     def __init__(self, state_dict, *, hidden, n_heads, n_layers, inter, vocab, dtype=torch.bfloat16, device="cuda:0",
                  rms_eps=1e-5, max_pos=4096, cache_cap=2048, max_new=512, max_prefill_rows=1024, img_ids=(),
-                 eos_id=2, lora_scaling=2.0):
+                 eos_id=2, lora_scaling=2.0, n_seq=1):
+        self.n_seq = int(n_seq)
         self.device = torch.device(device)
         self.dtype = dtype
         self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab = hidden, n_heads, n_layers, inter, vocab
@@ -80,11 +81,12 @@ class LlamaEngine:
     @classmethod
     def from_prebuilt(cls, *, embed, lm_head, final_norm, layers, hidden, n_heads, n_layers, inter, vocab,
                       dtype=torch.bfloat16, device="cuda:0", rms_eps=1e-5, max_pos=4096, cache_cap=2048, max_new=512,
-                      max_prefill_rows=1024, img_ids=(), eos_id=2):
+                      max_prefill_rows=1024, img_ids=(), eos_id=2, n_seq=1):
         """Engine over already merged/concatenated device tensors: ``layers`` is a list of
         ``(wqkv, wo, wgu, wdown, ln1, ln2)`` (used by the synthetic-weight benchmark, which
         creates the 13.5 GB of weights directly on the GPU)."""
         self = cls.__new__(cls)
+        self.n_seq = int(n_seq)
         self.device = torch.device(device)
         self.dtype = dtype
         self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab = hidden, n_heads, n_layers, inter, vocab
@@ -105,7 +107,8 @@ class LlamaEngine:
 
     def _init_engine(self, max_pos, rms_eps):
         cfg = _lib.LlamaConfig(self.hidden, self.n_heads, self.n_layers, self.inter, self.vocab, max_pos, rms_eps,
-                               ops.dt(self.dtype), self.cache_cap, self.max_new, len(self.img_ids), self.eos_id)
+                               ops.dt(self.dtype), self.cache_cap, self.max_new, len(self.img_ids), self.eos_id,
+                               self.n_seq)
         self._cfg = cfg
         w = _lib.LlamaWeights(self.embed.data_ptr(), self.lm_head.data_ptr(), self.final_norm.data_ptr(),
                               self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self._layers)
@@ -118,6 +121,7 @@ class LlamaEngine:
                                         C.byref(h)), "ss_llama_create")
         self._h = h
         self._views = {}
+        self._cur = 0
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -126,8 +130,15 @@ class LlamaEngine:
             self._h = None
 
     # ---- zero-copy views into the engine workspace -------------------------------------------
+    def select(self, seq):
+        """Address sequence slot ``seq`` (0 <= seq < n_seq) with the single-sequence methods
+        below (views, lengths, prefill, generate, kv_gather).  Returns self."""
+        check(lib().ss_llama_select(self._h, int(seq)), "ss_llama_select")
+        self._cur = int(seq)
+        return self
+
     def _buf(self, which, shape, dtype):
-        key = (which, tuple(shape), dtype)
+        key = (self._cur, which, tuple(shape), dtype)
         if key not in self._views:
             ptr = lib().ss_llama_buffer(self._h, which)
             base = self._ws.data_ptr()
@@ -216,6 +227,26 @@ class LlamaEngine:
         check(lib().ss_llama_generate(self._h, n_steps, int(last_prompt_id), arr, len(forced), C.byref(n),
                                       ops.stream()), "ss_llama_generate")
         return n.value
+
+    def generate_batch(self, n_steps, last_prompt_ids, forced=None, active=None):
+        """Greedy decode of all ``n_seq`` slots in lock-step (one sweep of the weights per token
+        for the whole batch).  ``last_prompt_ids[b]``, optional ``forced[b]`` token lists and
+        ``active[b]`` flags are per slot; returns the per-slot generated-token counts."""
+        S = self.n_seq
+        assert len(last_prompt_ids) == S
+        forced = [[] for _ in range(S)] if forced is None else [[int(t) for t in (f or [])] for f in forced]
+        ld = max(1, max(len(f) for f in forced))
+        flat = (C.c_int32 * (S * ld))()
+        for b, f in enumerate(forced):
+            for i, t in enumerate(f):
+                flat[b * ld + i] = t
+        nf = (C.c_int64 * S)(*[len(f) for f in forced])
+        last = (C.c_int32 * S)(*[int(t) for t in last_prompt_ids])
+        act = None if active is None else (C.c_int32 * S)(*[1 if a else 0 for a in active])
+        out = (C.c_int64 * S)()
+        check(lib().ss_llama_generate_batch(self._h, n_steps, last, flat, ld, nf, act, out, ops.stream()),
+              "ss_llama_generate_batch")
+        return [int(v) for v in out]
 
     def profile_decode(self, n_tokens=4):
         ms = (C.c_float * 8)()

@@ -187,6 +187,21 @@ def gemv(w, x, norm_w=None, eps=0.0, bias=None, residual=None, silu_mul=False):
     return y
 
 
+def gemv_batched(w, x, norm_w=None, eps=0.0, bias=None, residual=None, silu_mul=False):
+    """x [nb, K] (nb <= 4) -> y [nb, N]: one sweep of W for all rows."""
+    _req(w); _req(x)
+    N, K = w.shape
+    if silu_mul:
+        N //= 2
+    nb = x.shape[0]
+    y = torch.empty(nb, N, dtype=x.dtype, device=x.device)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0) | \
+          (EPI_SILU_MUL if silu_mul else 0)
+    check(lib().ss_gemv_batched(p(w), p(x), p(y), N, K, nb, p(norm_w), eps, p(bias), p(residual), epi, dt(x),
+                                stream()), "ss_gemv_batched")
+    return y
+
+
 def imgproc_argmax(logits, last_id, img_ids):
     """In-place processor + argmax; returns an int32 device scalar tensor."""
     _req(logits)

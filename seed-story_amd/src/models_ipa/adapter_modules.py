@@ -79,7 +79,8 @@ class SDXLAdapter(nn.Module):
                 image_tensor = torch.cat([image_tensor, torch.zeros_like(image_tensor)], dim=0)
             image_embeds = self.visual_encoder(image_tensor)
         elif return_negative:
-            image_embeds = torch.cat([image_embeds, self._negative_embeds(image_size, image_embeds)], dim=0)
+            neg = self._negative_embeds(image_size, image_embeds)
+            image_embeds = torch.cat([image_embeds, neg.expand(image_embeds.shape[0], -1, -1)], dim=0)
         if self.discrete_model is not None:
             image_embeds = self.discrete_model.encode_image_embeds(image_embeds)
         image_embeds, pooled_image_embeds = self.encode_image_embeds(image_embeds)
@@ -97,6 +98,11 @@ class SDXLAdapter(nn.Module):
                                                                  image_embeds=image_embeds, return_negative=True,
                                                                  image_size=input_image_size)
         generator = torch.Generator(self.device).manual_seed(seed) if seed is not None else None
+        if pos.shape[0] > 1 and "latents" not in kwargs:
+            # several stories rendered together: every image starts from the noise the reference draws for a
+            # single call with this seed (:455), so each equals its own batch-1 generate()
+            one = torch.randn((1, 4, height // 8, width // 8), generator=generator, device=pos.device, dtype=pos.dtype)
+            kwargs["latents"] = one.repeat(pos.shape[0], 1, 1, 1)
         return self.sdxl_pipe(prompt_embeds=pos.contiguous(), negative_prompt_embeds=neg.contiguous(),
                               pooled_prompt_embeds=pooled_pos.contiguous(),
                               negative_pooled_prompt_embeds=pooled_neg.contiguous(), guidance_scale=guidance_scale,

@@ -79,6 +79,52 @@ def test_llama_graph_equals_eager(golden):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("n_seq", [2, 3, 4])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llama_slot_batched_decode_equals_single(golden, n_seq, dtype):
+    """n_seq story slots decoded in lock-step (one sweep of the weights per token) must reproduce,
+    slot by slot, the batch-1 engine: token ids, hidden-state rows and the KV cache.  Slots get
+    different prompts, different forced prefixes, different stop points and one inactive slot."""
+    g, meta = golden
+    d = meta["LLAMA"]
+    tag = "llama_f32" if dtype == torch.float32 else "llama_bf16"
+    prompts = [synth.randint(40 + b, (19 + 5 * b,), 3, 250) for b in range(n_seq)]
+    prompts[0] = g[tag + ".ids"][0]
+    forced = [[7 + b, 9, 11 + b][: (b % 3) + 1] for b in range(n_seq)]
+    forced[-1] = [5, 2, 8]  # EOS (2) forced at step 2: this slot stops early
+    steps = 12
+    single, wd = [], None
+    for b in range(n_seq):
+        eng, wd = _engine(meta, dtype)
+        eng.prefill(wd["model.embed_tokens.weight"][prompts[b]])
+        n = eng.generate(steps, last_prompt_id=int(prompts[b][-1]), forced=forced[b])
+        kv = eng.lengths()[0]
+        single.append((n, eng.gen_ids[:n].tolist(), eng.hidden_rows[:max(n - 1, 0)].clone(),
+                       eng.k_cache[:, :, :kv].clone(), eng.v_cache[:, :, :kv].clone(), eng.lengths()))
+        del eng
+    eng, wd = _engine(meta, dtype, n_seq=n_seq)
+    for b in range(n_seq):
+        eng.select(b).prefill(wd["model.embed_tokens.weight"][prompts[b]])
+    ns = eng.generate_batch(steps, [int(p[-1]) for p in prompts], forced=forced)
+    assert ns[-1] == 2 and ns[0] == steps
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for b in range(n_seq):
+        n, ids, hid, k, v, lens = single[b]
+        eng.select(b)
+        assert ns[b] == n and eng.lengths() == lens, b
+        assert eng.gen_ids[:n].tolist() == ids, b
+        kv = lens[0]
+        assert rel(eng.hidden_rows[:max(n - 1, 0)], hid) < tol, b
+        assert rel(eng.k_cache[:, :, :kv], k) < tol and rel(eng.v_cache[:, :, :kv], v) < tol, b
+    # a second batch call with slot 0 inactive leaves slot 0 untouched and continues slot 1
+    before = (eng.select(0).lengths(), eng.gen_ids[:4].clone())
+    ns2 = eng.generate_batch(3, [1] * n_seq, forced=[[4, 4, 4]] * n_seq, active=[0] + [1] * (n_seq - 1))
+    assert ns2[0] == 0 and ns2[1] == 3
+    assert eng.select(0).lengths() == before[0] and torch.equal(eng.gen_ids[:4], before[1])
+    # 3 steps = 2 forwarded tokens (the step that hits the limit is sampled but not forwarded)
+    assert eng.select(1).lengths()[0] == single[1][5][0] + 2
+
+
 def test_llama_lora_merge(golden):
     """LoRA factors present: engine (merged once, fp32) vs the oracle's unmerged peft formula."""
     g, meta = golden

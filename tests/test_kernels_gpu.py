@@ -132,6 +132,45 @@ def test_gemv_silu_mul(ops, I, K, dtype):
     assert rel(y, ref) < (1e-5 if dtype == torch.float32 else 6e-3)
 
 
+@pytest.mark.parametrize("nb", [2, 3, 4])
+@pytest.mark.parametrize("N,K", [(512, 256), (4096, 4096), (4096, 11008), (1000, 1664)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemv_batched_rows_match_single(ops, nb, N, K, dtype):
+    """Lock-step decode of nb story slots: row b of the batched sweep == the batch-1 kernel on row b
+    (same per-lane summation order in the register path; LDS-staged path within rounding)."""
+    w = dev(synth.normal_like(70, (N, K), 0.05, dtype=dtype))
+    x = dev(synth.normal_like(71, (nb, K), 1.0, dtype=dtype))
+    res = dev(synth.normal_like(72, (nb, N), 1.0, dtype=dtype))
+    nw = dev(synth.normal_like(73, (K,), 0.1, 1.0, dtype=dtype))
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    for kw in ({}, {"residual": True}, {"norm": True}):
+        r = res if kw.get("residual") else None
+        n = nw if kw.get("norm") else None
+        yb = ops.gemv_batched(w, x, norm_w=n, eps=1e-5, residual=r)
+        for b in range(nb):
+            y1 = ops.gemv(w, x[b].contiguous(), norm_w=n, eps=1e-5, residual=None if r is None else r[b].contiguous())
+            assert rel(yb[b], y1) < tol, (kw, b)
+        xr = x.float().cpu()
+        if n is not None:
+            xr = torch.stack([O.rmsnorm(x[b].cpu(), nw.cpu(), 1e-5) for b in range(nb)]).float()
+        ref = (xr @ w.float().cpu().t()).to(dtype)
+        if r is not None:
+            ref = (ref + res.cpu()).to(dtype)
+        assert rel(yb, ref) < tol, kw
+
+
+@pytest.mark.parametrize("nb", [2, 4])
+def test_gemv_batched_silu(ops, nb):
+    I, K = 11008, 4096
+    dtype = torch.bfloat16
+    w = dev(synth.normal_like(74, (2 * I, K), 0.05, dtype=dtype))
+    x = dev(synth.normal_like(75, (nb, K), 1.0, dtype=dtype))
+    yb = ops.gemv_batched(w, x, silu_mul=True)
+    for b in range(nb):
+        y1 = ops.gemv(w, x[b].contiguous(), silu_mul=True)
+        assert rel(yb[b], y1) < 6e-3
+
+
 GEMM_SHAPES = [(1, 64, 64), (37, 100, 256), (65, 4096, 4096), (114, 1000, 4096), (343, 768, 512),
                (130, 4992, 1664), (256, 1664, 608), (300, 256, 8192), (1024, 512, 1664)]
 

@@ -180,6 +180,36 @@ def test_pipeline_euler_cfg_tiny():
     assert (img.cpu().float() - ref_img.float()).abs().mean() < 1.0       # uint8 levels
 
 
+def test_pipeline_batched_images_equal_single_calls():
+    """Several stories' images denoised together (UNet batch 2B = [B uncond; B cond]): image b of the
+    batch equals its own batch-1 pipeline call (oracle-checked above), fp32."""
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, StableDiffusionXLPipeline
+    m, wd, c = _unet(torch.float32)
+    vc = S.TINY_VAE
+    vae = AutoencoderKL(vc)
+    vae.load_state_dict(S.synth_weights(S.vae_decoder_shapes(vc), 2))
+    vae = vae.to(DEV, torch.float32)
+    pipe = StableDiffusionXLPipeline(vae=vae, unet=m, scheduler=EulerDiscreteScheduler())
+    B = 3
+    cp, cn = synth.normal_like(130, (B, 8, 128), 1.0).to(DEV), synth.normal_like(131, (B, 8, 128), 1.0).to(DEV)
+    pp, pn = synth.normal_like(132, (B, 80), 1.0).to(DEV), synth.normal_like(133, (B, 80), 1.0).to(DEV)
+    noise = synth.normal_like(134, (B, 4, 8, 8), 1.0).to(DEV)
+    kw = dict(guidance_scale=7.5, num_inference_steps=4, height=64, width=64)
+    lat = pipe(prompt_embeds=cp, negative_prompt_embeds=cn, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=pn,
+               latents=noise, output_type="latent", **kw).images
+    img = pipe(prompt_embeds=cp, negative_prompt_embeds=cn, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=pn,
+               latents=noise, output_type="pt", **kw).images
+    assert lat.shape == (B, 4, 8, 8) and img.shape == (B, 64, 64, 3)
+    for b in range(B):
+        sl = slice(b, b + 1)
+        one = pipe(prompt_embeds=cp[sl], negative_prompt_embeds=cn[sl], pooled_prompt_embeds=pp[sl],
+                   negative_pooled_prompt_embeds=pn[sl], latents=noise[sl], output_type="latent", **kw).images
+        assert rel(lat[sl], one) < 2e-4, b
+        one_img = pipe(prompt_embeds=cp[sl], negative_prompt_embeds=cn[sl], pooled_prompt_embeds=pp[sl],
+                       negative_pooled_prompt_embeds=pn[sl], latents=noise[sl], output_type="pt", **kw).images
+        assert (img[b].float() - one_img.float()).abs().max() <= 1
+
+
 def test_resampler_xlv2(golden):
     from src.models_ipa.resampler import ResamplerXLV2
     g, meta = golden

@@ -103,7 +103,7 @@ def bench_attn():
     OUT["attn"] = res
 
 
-def make_7b_engine(n_layers=32, cache_cap=2048, max_new=512, max_rows=1024):
+def make_7b_engine(n_layers=32, cache_cap=2048, max_new=512, max_rows=1024, n_seq=1):
     from seedstory.llama import LlamaEngine
     H, I, V = 4096, 11008, 32066
     dt = torch.bfloat16
@@ -116,7 +116,67 @@ def make_7b_engine(n_layers=32, cache_cap=2048, max_new=512, max_rows=1024):
     return LlamaEngine.from_prebuilt(embed=rnd(V, H), lm_head=rnd(V, H), final_norm=torch.ones(H, device=DEV, dtype=dt),
                                      layers=layers, hidden=H, n_heads=32, n_layers=n_layers, inter=I, vocab=V, dtype=dt,
                                      device=DEV, cache_cap=cache_cap, max_new=max_new, max_prefill_rows=max_rows,
-                                     img_ids=list(range(32000, 32066)))
+                                     img_ids=list(range(32000, 32066)), n_seq=n_seq)
+
+
+def bench_slots():
+    """Lock-step decode of n_seq story slots: per-token time and per-story token rate."""
+    res = {}
+    shapes = [("qkv", 12288, 4096, {}), ("gateup", 11008, 4096, {"silu_mul": True}), ("down", 4096, 11008, {})]
+    for name, N, K, kw in shapes:
+        rows = N * 2 if kw.get("silu_mul") else N
+        ncopy = max(2, int(600e6 // (rows * K * 2)) + 1)
+        ws = [torch.randn(rows, K, device=DEV, dtype=torch.bfloat16) * 0.02 for _ in range(ncopy)]
+        for nb in (1, 2, 3, 4):
+            x = torch.randn(nb, K, device=DEV, dtype=torch.bfloat16)
+            for regpacks in (16, 32):
+                if nb * (K // 512) <= 16 and regpacks == 32:
+                    continue
+                _lib.set_tuning("gemv_x_reg_packs", regpacks)
+                st = {"i": 0}
+
+                def f():
+                    st["i"] += 1
+                    ops.gemv_batched(ws[st["i"] % ncopy], x, **kw)
+
+                def fn():
+                    st["i"] += 1
+                    ops.gemv_batched(ws[st["i"] % ncopy], x, norm_w=nw, eps=1e-5, **kw)
+                nw = torch.ones(K, device=DEV, dtype=torch.bfloat16)
+                ms = timeit(f, iters=30)
+                msn = timeit(fn, iters=30)
+                res["gemv_%s_nb%d_reg%d" % (name, nb, regpacks)] = dict(ms=round(ms, 4), GBps=round(rows * K * 2 / ms / 1e6, 1), norm_GBps=round(rows * K * 2 / msn / 1e6, 1))
+                print(name, nb, regpacks, res["gemv_%s_nb%d_reg%d" % (name, nb, regpacks)], flush=True)
+        del ws
+    _lib.set_tuning("gemv_x_reg_packs", 16)
+    for n_seq in (1, 2, 4):
+        eng = make_7b_engine(n_seq=n_seq)
+        S = 343
+        for b in range(n_seq):
+            eng.select(b).prefill(torch.randn(S + 3 * b, 4096, device=DEV, dtype=torch.bfloat16) * 0.02)
+        forced = [torch.randint(3, 32000, (115,)).tolist() for _ in range(n_seq)]
+        for regpacks in ((16,) if n_seq <= 2 else (16, 32)):
+            _lib.set_tuning("gemv_x_reg_packs", regpacks)
+            eng.generate_batch(8, [5] * n_seq, [f[:8] for f in forced])
+            for b in range(n_seq):
+                eng.select(b).set_lengths(S + 3 * b, S + 3 * b)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ns = eng.generate_batch(115, [5] * n_seq, forced)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t0
+            for b in range(n_seq):
+                eng.select(b).set_lengths(S + 3 * b, S + 3 * b)
+            key = "slots%d_reg%d" % (n_seq, regpacks)
+            res[key] = dict(tok_ms=round(dtm * 1e3 / ns[0], 4), per_story_tok_ms=round(dtm * 1e3 / ns[0] / n_seq, 4),
+                            profile=eng.profile_decode(4))
+            for b in range(n_seq):
+                eng.select(b).set_lengths(S + 3 * b, S + 3 * b)
+            print(key, res[key], flush=True)
+        _lib.set_tuning("gemv_x_reg_packs", 16)
+        del eng
+        torch.cuda.empty_cache()
+    OUT["slots"] = res
 
 
 def bench_decode():
@@ -251,7 +311,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for w in which:
         try:
-            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode, "sdxl": bench_sdxl, "gemm_unet": bench_gemm_unet}[w]()
+            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode, "sdxl": bench_sdxl, "slots": bench_slots, "gemm_unet": bench_gemm_unet}[w]()
         except Exception as ex:  # keep going: one broken kernel must not hide the other numbers
             import traceback
             traceback.print_exc()
