@@ -205,6 +205,34 @@ def test_gemm_every_tile_config(ops, cfg):
     assert rel(y, a.float() @ w.float().t()) < 4e-3
 
 
+@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23])
+@pytest.mark.parametrize("M,N,K", [(200, 300, 512), (1024, 640, 1280), (333, 1000, 64), (4096, 256, 2560), (130, 72, 192)])
+def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
+    """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-23 software-pipelined) on ragged and
+    tile-aligned shapes, with the bias / residual / GELU / GEGLU-pair epilogues."""
+    from seedstory import _lib
+    dtype = torch.bfloat16
+    a = dev(synth.normal_like(180, (M, K), 1.0, dtype=dtype))
+    w = dev(synth.normal_like(181, (N, K), 0.05, dtype=dtype))
+    bias = dev(synth.normal_like(182, (N,), 0.5, dtype=dtype))
+    res = dev(synth.normal_like(183, (M, N), 1.0, dtype=dtype))
+    ref = a.float() @ w.float().t()
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        y0 = ops.gemm(a, w)
+        y1 = ops.gemm(a, w, bias=bias, residual=res)
+        y2 = ops.gemm(a, w, bias=bias, gelu=True)
+        y3 = ops.gemm_geglu(a, w, bias) if N % 2 == 0 else None
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(y0, ref) < 4e-3
+    assert rel(y1, ((ref + bias.float()).to(dtype) + res).float()) < 4e-3
+    assert rel(y2, torch.nn.functional.gelu((ref + bias.float()).to(dtype))) < 6e-3
+    if y3 is not None:
+        full = (ref + bias.float()).to(dtype).float()
+        assert rel(y3, full[:, 0::2] * torch.nn.functional.gelu(full[:, 1::2].to(dtype)).float()) < 8e-3
+
+
 def attn_ref(q, k, v, n_heads, scale, causal_br):
     """fp32 softmax attention on [B, L, E] with packed heads."""
     B, Lq, E = q.shape

@@ -55,6 +55,33 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23])
+@pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
+                                                   (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
+def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
+    """Implicit-GEMM conv through every LDS-DMA tile configuration (20-23: the software-pipelined kernel with
+    EXEC-masked DMA + direct zero fill for the padding taps)."""
+    from seedstory import _lib, ops
+    from seedstory.diffusion import _conv_w
+    dtype = torch.bfloat16
+    x = synth.normal_like(201, (B, Ci, H, W), 1.0, dtype=dtype)
+    w = synth.normal_like(202, (Co, Ci, 3, 3), 1.0 / math.sqrt(9 * Ci), dtype=dtype)
+    b = synth.normal_like(203, (Co,), 0.5, dtype=dtype)
+    tv = synth.normal_like(204, (B, Co), 0.5, dtype=dtype)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xi, w.float(), b.float(), stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = synth.normal_like(205, (B, Co, Ho, Wo), 1.0, dtype=dtype)
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        y, ho, wo = ops.conv3x3(nhwc(x).to(DEV), _conv_w(w).to(DEV), B, H, W, stride=stride, upsample=up, bias=b.to(DEV),
+                                rowvec=tv.to(DEV), residual=nhwc(res).to(DEV))
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert (ho, wo) == (Ho, Wo)
+    assert rel(nchw(y.cpu(), B, Ho, Wo), ref + tv.float()[:, :, None, None] + res.float()) < 1e-2
+
+
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 5, 7, 32), (1, 320, 16, 16, 32), (2, 128, 33, 9, 32), (1, 1920, 4, 4, 32)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_groupnorm_silu(B, C, H, W, G, dtype):

@@ -237,27 +237,27 @@ def bench_decode():
 
 def bench_gemm_unet():
     res = []
-    shapes = [(2048, 3840, 1280), (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120), (8192, 1920, 640),
-              (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560), (4096, 4096, 4096), (1024, 4992, 1664),
-              (1024, 8192, 1664), (343, 12288, 4096)]
+    shapes = [(8192, 3840, 1280), (8192, 1280, 1280), (8192, 10240, 1280), (8192, 1280, 5120), (32768, 1920, 640),
+              (32768, 640, 640), (32768, 5120, 640), (32768, 640, 2560), (2048, 3840, 1280), (2048, 1280, 1280),
+              (2048, 10240, 1280), (2048, 1280, 5120), (4096, 4096, 4096), (1024, 4992, 1664), (343, 12288, 4096)]
     for M, N, K in shapes:
         a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
         w = torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         row = dict(M=M, N=N, K=K)
-        for cfg in (8, 10, 15):
+        for cfg in (8, 10, 15, 20, 21, 22, 23):
             _lib.set_tuning("gemm_cfg", cfg)
             ms = timeit(lambda: ops.gemm(a, w, out=out), iters=10)
             row["cfg%d" % cfg] = round(2.0 * M * N * K / ms / 1e9)
         res.append(row)
         print(row, flush=True)
-    convs = [(2, 128, 128, 320, 320), (2, 64, 64, 640, 640), (2, 32, 32, 1280, 1280), (2, 32, 32, 2560, 1280),
-             (2, 64, 64, 1920, 640), (2, 128, 128, 960, 320), (1, 1024, 1024, 128, 128), (1, 512, 512, 256, 256)]
+    convs = [(8, 128, 128, 320, 320), (8, 64, 64, 640, 640), (8, 32, 32, 1280, 1280), (8, 32, 32, 2560, 1280),
+             (8, 64, 64, 1920, 640), (8, 128, 128, 960, 320), (1, 1024, 1024, 128, 128), (1, 512, 512, 256, 256)]
     for B, H, W, Ci, Co in convs:
         x = torch.randn(B * H * W, Ci, device=DEV, dtype=torch.bfloat16)
         w = torch.randn(Co, 9 * Ci, device=DEV, dtype=torch.bfloat16) * 0.02
         row = dict(conv=(B, H, W, Ci, Co))
-        for cfg in (8, 10, 12, 13, 14, 15, 16, 17):
+        for cfg in (8, 10, 15, 20, 21, 22, 23):
             _lib.set_tuning("gemm_cfg", cfg)
             ms = timeit(lambda: ops.conv3x3(x, w, B, H, W), iters=5)
             row["cfg%d" % cfg] = round(2.0 * B * H * W * Co * 9 * Ci / ms / 1e9)
