@@ -24,6 +24,7 @@
 
 namespace ss {
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     static constexpr int kK = 32;
@@ -31,12 +32,23 @@ template <> struct Mma<bf16_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
+    // in-place form with the accumulator pinned to its VGPRs (see gemm_sp_kernel<.., NH = 2>)
+    static __device__ __forceinline__ void run_inplace(const uint4& a, const uint4& b, f32x4_t& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+v"(c)
+                     : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
+    }
 };
 template <> struct Mma<f16_t> {
     static constexpr int kK = 32;
     static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                       __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void run_inplace(const uint4& a, const uint4& b, f32x4_t& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                     : "+v"(c)
+                     : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
     }
 };
 
@@ -277,6 +289,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // Epilogue shared by the LDS-DMA kernels: acc[i][j] is the 16x16 fragment at rows m_base + j*16.., columns
 // n_base + i*16.. (lane l15 -> row, lane group grp -> 4 consecutive columns); same contract as gemm_kernel.
+// A lane owns 4 consecutive columns of one row per fragment, so bias / rowvec / residual / C move as one 8-byte
+// access each when the 4 columns are in range and the operands are 8-byte aligned (every shape on the path).
+// Fragment columns are processed one i at a time (sched_barrier): the FM fragments of a column block have their
+// loads in flight together, but live ranges do not span the whole tile (32 fragments at 256x256).
+template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
+    if constexpr (Tr<T>::kVec == 8) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        float f[8];
+        unpack<T>(make_uint4(u.x, u.y, 0, 0), f);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+    } else {
+        const float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+}
+
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                               int l15, int grp) {
@@ -284,13 +313,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
     T* __restrict__ C = (T*)g.C;
     const T* bias = (const T*)g.bias;
     const T* res = (const T*)g.residual;
+    constexpr size_t AL = 4 * sizeof(T) - 1;   // alignment mask of a 4-element access
+    const bool vec_ok = (((size_t)g.bias | (size_t)g.residual | (size_t)g.rowvec) & AL) == 0 &&
+                        ((g.ldr | g.rowvec_ld) & 3) == 0;
+    const bool vec_c = ((size_t)g.C & AL) == 0 && (g.ldc & 3) == 0;
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         const int n0 = n_base + i * 16 + grp * 4;
+        const bool full = n0 + 3 < N;
+        const bool fast = full && vec_ok;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (g.epi & SS_EPI_BIAS) {
+            if (fast) ld4<T>(bias + n0, bv);
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n0 + r < N) bv[r] = Tr<T>::ld(bias + n0 + r);
+                for (int r = 0; r < 4; ++r) if (n0 + r < N) bv[r] = Tr<T>::ld(bias + n0 + r);
+            }
         }
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
@@ -300,24 +338,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (g.rowvec) {
                 const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
+                if (fast) ld4<T>(rp + n0, rv);
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
+                    for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[i][j][r] + bv[r];
                 if (g.epi & SS_EPI_GELU) t = gelu_erf(Tr<T>::rnd(t));
                 v[r] = Tr<T>::rnd(t);
-                if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);
+                if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);   // h = conv(x) + temb[:, :, None, None]
             }
             if (g.epi & SS_EPI_RESIDUAL) {
+                if (fast) {
+                    float rr[4];
+                    ld4<T>(res + (int64_t)m * g.ldr + n0, rr);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
+                }
             }
             if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
                 const float o0 = v[0] * Tr<T>::rnd(gelu_erf(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_erf(v[3]));
-                if (n0 + 3 < N && ((g.ldc & 1) == 0)) {
+                if (full && ((g.ldc & 1) == 0) && (((size_t)g.C & 3) == 0) && Tr<T>::kVec == 8) {
                     float pk[8] = {o0, o1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<uint32_t*>(C + (int64_t)m * g.ldc + (n0 >> 1)) = pack<T>(pk).x;
                 } else {
@@ -326,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 }
                 continue;
             }
-            if (n0 + 3 < N && ((g.ldc & 3) == 0)) {
+            if (full && vec_c && Tr<T>::kVec == 8) {
                 float pk[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
                 const uint4 u = pack<T>(pk);
                 *reinterpret_cast<uint2*>(C + (int64_t)m * g.ldc + n0) = make_uint2(u.x, u.y);
@@ -336,6 +384,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     if (n0 + r < N) Tr<T>::st(C + (int64_t)m * g.ldc + n0 + r, v[r]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -497,7 +546,7 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const void* sbase, uint32_
         : "memory");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+template <typename T, int BM, int BN, int WM, int WN, int NH, bool CONV>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -592,13 +641,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
     // for every fragment, so ks = 1 is the ks = 0 address XOR 64 and fragments are 2048 B apart ------------------
     const uint32_t fa0 = (uint32_t)((wm * TM + l15) * 128 + ((grp ^ (l15 & 7)) << 4));
     const uint32_t fw0 = (uint32_t)((BM + wn * TN + l15) * 128 + ((grp ^ (l15 & 7)) << 4));
-    auto read_frags = [&](uint4 (&fa)[FM], uint4 (&fw)[FN], int buf, int ks) {
+    // A K tile is consumed in P = 2*NH phases (ks, h): k-step ks of the tile, h-th 1/NH of the wave's A rows.
+    // Phase p multiplies A set (p & 1) with W set (ks & 1); the operands of phase p+1 are read while the MFMAs
+    // of phase p run.  NH = 2 halves the fragment registers of a 128-row wave tile (64 instead of 96 VGPRs).
+    constexpr int FMH = FM / NH, P = 2 * NH;
+    static_assert(FM % NH == 0, "A fragments must split evenly");
+    uint4 fa[2][FMH], fw[2][FN];
+    auto read_phase = [&](int buf, int p) {   // operands of phase p of the tile in buffer `buf`
+        const int ks = p / NH, h = p % NH;
         const char* b = smem_raw + buf * TILE_BYTES;
         const uint32_t xa = ks ? (fa0 ^ 64u) : fa0, xw = ks ? (fw0 ^ 64u) : fw0;
+        if (h == 0) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const uint4*>(b + xw + i * 2048);
+            for (int i = 0; i < FN; ++i) fw[ks & 1][i] = *reinterpret_cast<const uint4*>(b + xw + i * 2048);
+        }
 #pragma unroll
-        for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(b + xa + j * 2048);
+        for (int j = 0; j < FMH; ++j) fa[p & 1][j] = *reinterpret_cast<const uint4*>(b + xa + (h * FMH + j) * 2048);
     };
 
     f32x4_t acc[FN][FM];
@@ -606,37 +664,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto mma_all = [&](const uint4 (&fa)[FM], const uint4 (&fw)[FN]) {
+    auto mma_phase = [&](int p) {
+        const int ks = p / NH, h = p % NH;
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = Mma<T>::run(fw[i], fa[j], acc[i][j]);
+            for (int j = 0; j < FMH; ++j) {
+                // 128-row wave tiles (NH = 2): the allocator otherwise shuttles the 128 accumulator registers
+                // through copies around every MFMA; the asm form pins accumulate-in-place
+                if constexpr (NH > 1) Mma<T>::run_inplace(fw[ks & 1][i], fa[p & 1][j], acc[i][h * FMH + j]);
+                else acc[i][h * FMH + j] = Mma<T>::run(fw[ks & 1][i], fa[p & 1][j], acc[i][h * FMH + j]);
+            }
     };
 
-    uint4 fa_a[FM], fw_a[FN], fa_b[FM], fw_b[FN];   // set a = ks 0 fragments, set b = ks 1 fragments
     issue_tile(0, 0);
     if (ntiles > 1) issue_tile(1, 1);
     if (ntiles > 1) wait_vmcnt<IA + IW>(); else wait_vmcnt<0>();   // tile 0 landed (tile 1 may still fly)
     __syncthreads();
-    read_frags(fa_a, fw_a, 0, 0);
-    // one K tile: [read ks1 | MFMA ks0] -> barrier (tile t+1 landed, buffer of tile t free) -> [DMA t+2, read ks0 of t+1 | MFMA ks1]
+    read_phase(0, 0);
+    if constexpr (NH > 1) asm volatile("s_nop 7" ::: "memory");   // asm MFMAs are opaque to the hazard recognizer
+    // one K tile: phases 0 .. P-2 each prefetch their successor; before the LAST phase's MFMAs comes the tile's one
+    // barrier (tile t+1 landed, buffer of tile t drained), the DMA of tile t+2 and the prefetch of tile t+1's phase 0.
     // (sched_barrier pins the phase order: left alone, the scheduler sinks the MFMAs behind the barrier and the
     // fragment reads in front of their consumers, which re-exposes the LDS latency this layout exists to hide)
     auto step = [&](int t, int buf) {
-        read_frags(fa_b, fw_b, buf, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_all(fa_a, fw_a);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my ks1 fragments are in registers: buffer `buf` is drained
-            wait_vmcnt<0>();                                       // my share of tile t+1 has landed
-            __syncthreads();
-            if (t + 2 < ntiles) issue_tile(t + 2, buf);
-            read_frags(fa_a, fw_a, buf ^ 1, 0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (p < P - 1) {
+                read_phase(buf, p + 1);
+            } else if (t + 1 < ntiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all my fragments of tile t are in registers
+                wait_vmcnt<0>();                                       // my share of tile t+1 has landed
+                __syncthreads();
+                if (t + 2 < ntiles) issue_tile(t + 2, buf);
+                read_phase(buf ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_phase(p);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_all(fa_b, fw_b);
-        __builtin_amdgcn_sched_barrier(0);
     };
     int t = 0;
     for (; t + 1 < ntiles; t += 2) {
@@ -644,11 +710,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
         step(t + 1, 1);
     }
     if (t < ntiles) step(t, 0);
+    if constexpr (NH > 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results settle before VALU reads them
 
     gemm_epilogue<T, FM, FN>(g, acc, m_blk + wm * TM, n_blk + wn * TN, l15, grp);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NH = 1>
 static int gemm_sp_launch_cfg(const GemmArgs& g, hipStream_t s) {
     if constexpr (Tr<T>::kVec == 8) {
         const bool conv = g.conv_Cin > 0;
@@ -660,13 +727,13 @@ static int gemm_sp_launch_cfg(const GemmArgs& g, hipStream_t s) {
         const size_t lds = (size_t)2 * (BM + BN) * 128;
         dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
         if (lds > 64 * 1024) {
-            if (conv) hipFuncSetAttribute((const void*)gemm_sp_kernel<T, BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            else hipFuncSetAttribute((const void*)gemm_sp_kernel<T, BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (conv) hipFuncSetAttribute((const void*)gemm_sp_kernel<T, BM, BN, WM, WN, NH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            else hipFuncSetAttribute((const void*)gemm_sp_kernel<T, BM, BN, WM, WN, NH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         if (conv)
-            hipLaunchKernelGGL((gemm_sp_kernel<T, BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, g);
+            hipLaunchKernelGGL((gemm_sp_kernel<T, BM, BN, WM, WN, NH, true>), grid, dim3(64 * WM * WN), lds, s, g);
         else
-            hipLaunchKernelGGL((gemm_sp_kernel<T, BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, g);
+            hipLaunchKernelGGL((gemm_sp_kernel<T, BM, BN, WM, WN, NH, false>), grid, dim3(64 * WM * WN), lds, s, g);
         SS_LAUNCH_CHECK("gemm_sp");
         return SS_OK;
     } else {
@@ -713,6 +780,8 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
         case 21: return gemm_sp_launch_cfg<T, 128, 64, 2, 2>(g, s);
         case 22: return gemm_sp_launch_cfg<T, 64, 64, 2, 2>(g, s);
         case 23: return gemm_sp_launch_cfg<T, 256, 128, 4, 2>(g, s);
+        case 24: return gemm_sp_launch_cfg<T, 256, 256, 2, 4, 2>(g, s);   // 8 waves, 128x64 per wave, A in halves
+        case 25: return gemm_sp_launch_cfg<T, 256, 128, 2, 2, 2>(g, s);   // 4 waves, 128x64 per wave
         default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
     }
 }
@@ -762,7 +831,8 @@ static int autotuned_cfg(const GemmArgs& g0, hipStream_t s) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     // 8/15/10 = double-buffered DMA kernels (128x128, 128x64, 64x64), 20/21/23 = software-pipelined DMA kernels
     // (128x128, 128x64, 256x128); the pipelined ones win every conv (+20-40 %) and the widest plain GEMMs
-    const int cands[6] = {8, 15, 10, 20, 21, 23};
+    // 24 = 256x256 with 128x64 wave tiles (accumulators pinned): best on long-K problems (3x3 convs, ff2)
+    const int cands[7] = {8, 15, 10, 20, 21, 23, 24};
     int best = fallback;
     float best_ms = 1e30f;
     for (int c : cands) {
