@@ -245,7 +245,8 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, uint32_t lds_base) 
 }
 
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void flash_attn2_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 3 : 2)))
+void flash_attn2_kernel(const AttnArgs a) {
     constexpr int V = 8;
     constexpr int BQ2 = 128;             // query rows per block: 4 waves x 32
     constexpr int CPR = HD / V;          // 16-byte chunks per key row
@@ -342,32 +343,45 @@ __global__ __launch_bounds__(256) void flash_attn2_kernel(const AttnArgs a) {
             }
         }
         // ---- online softmax (log2 domain) --------------------------------------------------------------
+        // The softmax is the VALU-bound part of the kernel (32 scores per lane per tile against 32 MFMAs), so
+        // full tiles take a mask-free path, exp2 is the raw v_exp_f32 (arguments <= 0: no range fix-up
+        // needed).
         uint4 pfrag[2][NKB / 2];
+        const bool need_mask = a.causal_br || (t0 + kBKV > a.kv_len);   // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            // running max m_run is kept in RAW score units; p = exp2(s*sl2 - m*sl2) is one FMA + v_exp_f32
             float tmax = -1e30f;
-            bool msk[NKB][4];
+            if (need_mask) {
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kg = t0 + kb * 16 + grp * 4 + r;
-                    const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
-                    msk[kb][r] = ok;
-                    const float sv = ok ? s[qb][kb][r] * sl2 : -1e30f;
-                    s[qb][kb][r] = sv;
-                    tmax = fmaxf(tmax, sv);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int kg = t0 + kb * 16 + grp * 4 + r;
+                        const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
+                        const float sv = ok ? s[qb][kb][r] : -1e30f;
+                        s[qb][kb][r] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run[qb], tmax);
-            const float alpha = exp2f(m_run[qb] - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
+            // masked scores sit at -1e30, so exp2((s - m)*sl2) is exactly 0 for them — unless the whole row is
+            // masked (m = -1e30 too); subtracting at least -1e29 keeps that case at exp2(-huge) = 0 as well
+            const float nm = -fmaxf(m_new, -1e29f) * sl2;
             float lsum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = msk[kb][r] ? exp2f(s[qb][kb][r] - m_new) : 0.f;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], sl2, nm));
                     s[qb][kb][r] = p;
                     lsum += p;
                 }
@@ -396,11 +410,8 @@ __global__ __launch_bounds__(256) void flash_attn2_kernel(const AttnArgs a) {
                 const int dcol = db * 16 + (l15 & 3) * 4;
                 const v4s_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(Vb + kr0 * ROWB + dcol * 2));
                 const v4s_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(Vb + (kr0 + 16) * ROWB + dcol * 2));
-                uint4 vfrag;
-                vfrag.x = (uint32_t)(uint16_t)v0[0] | ((uint32_t)(uint16_t)v0[1] << 16);
-                vfrag.y = (uint32_t)(uint16_t)v0[2] | ((uint32_t)(uint16_t)v0[3] << 16);
-                vfrag.z = (uint32_t)(uint16_t)v1[0] | ((uint32_t)(uint16_t)v1[1] << 16);
-                vfrag.w = (uint32_t)(uint16_t)v1[2] | ((uint32_t)(uint16_t)v1[3] << 16);
+                const uint2 w0 = __builtin_bit_cast(uint2, v0), w1 = __builtin_bit_cast(uint2, v1);
+                const uint4 vfrag = make_uint4(w0.x, w0.y, w1.x, w1.y);
                 o[0][db] = AttnMma<T>::run(vfrag, pfrag[0][kp2], o[0][db]);
                 o[1][db] = AttnMma<T>::run(vfrag, pfrag[1][kp2], o[1][db]);
             }

@@ -80,7 +80,9 @@ def bench_attn():
     res = []
     for (B, H, hd, Lq, Lk, causal) in [(1, 32, 128, 343, 343, True), (1, 32, 128, 913, 913, True),
                                         (1, 32, 128, 65, 900, True), (1, 16, 104, 1024, 1024, False),
-                                        (8, 32, 128, 64, 256, False)]:
+                                        (8, 32, 128, 64, 256, False), (8, 10, 64, 4096, 4096, False),
+                                        (8, 20, 64, 1024, 1024, False), (8, 10, 64, 4096, 64, False),
+                                        (8, 20, 64, 1024, 64, False), (2, 10, 64, 4096, 4096, False)]:
         E = H * hd
         q = torch.randn(B, Lq, E, device=DEV, dtype=torch.bfloat16)
         k = torch.randn(B, Lk, E, device=DEV, dtype=torch.bfloat16)
