@@ -16,12 +16,19 @@ __device__ __forceinline__ float gelu_d(float v) { return 0.5f * v * (1.0f + erf
 //   pass 2: y = (x - mean) * rstd * gamma[c] + beta[c]  (+ SiLU), rounded once to T
 // (torch GroupNorm computes in fp32 and rounds the result; SiLU then rounds again.)
 // =====================================================================================
+// fast sigmoid-linear unit on the hardware transcendentals: x * rcp(1 + exp2(-x * log2 e))
+__device__ __forceinline__ float silu_fast(float g) {
+    return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
+
+// Both passes give every thread ONE fixed 16-byte channel pack and a strided set of pixel rows of one image,
+// so everything that depends on the channel (group index, gamma/beta, mean/rstd) is hoisted out of the row loop
+// and the loop body is a 16-byte load + 2 (stats) or ~4 (apply) VALU ops per element: both passes run at the
+// HBM rate instead of being bound by per-element integer divisions and LDS atomics.
+//   thread t of a block: pack p = pc + t % cw, first row r0 + t / cw, row stride 256 / cw   (cw = packs per chunk)
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
                                                               int HW, int C, int G, int rows_per_block) {
-    // One block = a range of pixels x ALL channels (full 16-byte coalesced rows, any channels-per-group,
-    // e.g. 10 for C=320).  Per-pack partial sums go to LDS atomics (<= 4-way same-address contention),
-    // then 2*G global fp32 atomics per block.
     constexpr int V = Tr<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sh = reinterpret_cast<float*>(smem_raw);  // [G][2]
@@ -32,26 +39,49 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.f;
     __syncthreads();
     const T* xb = x + ((int64_t)b * HW) * C;
-    const int total = (r1 - r0) * ppr;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int r = r0 + i / ppr, p = i % ppr;
-        float f[V];
-        unpack<T>(ld16(xb + (int64_t)r * C + p * V), f);
+    for (int pc = 0; pc < ppr; pc += 256) {
+        const int cw = min(256, ppr - pc);
+        const int rip = 256 / cw;                      // rows in flight per block pass
+        const int ry = threadIdx.x / cw, p = pc + threadIdx.x % cw;
+        if (ry >= rip) continue;
+        float s1[V], s2[V];                            // per-channel partial sums of this thread's pack
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        const T* xp = xb + (int64_t)p * V;
+        int r = r0 + ry;
+        for (; r + rip < r1; r += 2 * rip) {           // two independent loads in flight
+            float f[V], h[V];
+            const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
+            unpack<T>(u0, f);
+            unpack<T>(u1, h);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]);
+                s1[j] += h[j]; s2[j] = fmaf(h[j], h[j], s2[j]);
+            }
+        }
+        if (r < r1) {
+            float f[V];
+            unpack<T>(ld16(xp + (int64_t)r * C), f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+        }
+        // fold the pack's channels into their groups (consecutive channels of one group are summed first)
         int g = (p * V) / cg;
-        float s1 = 0.f, s2 = 0.f;
+        float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int gj = (p * V + j) / cg;
             if (gj != g) {
-                atomicAdd(sh + 2 * g, s1);
-                atomicAdd(sh + 2 * g + 1, s2);
-                g = gj; s1 = 0.f; s2 = 0.f;
+                atomicAdd(sh + 2 * g, a1);
+                atomicAdd(sh + 2 * g + 1, a2);
+                g = gj; a1 = 0.f; a2 = 0.f;
             }
-            s1 += f[j];
-            s2 = fmaf(f[j], f[j], s2);
+            a1 += s1[j];
+            a2 += s2[j];
         }
-        atomicAdd(sh + 2 * g, s1);
-        atomicAdd(sh + 2 * g + 1, s2);
+        atomicAdd(sh + 2 * g, a1);
+        atomicAdd(sh + 2 * g + 1, a2);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(stats + (int64_t)b * G * 2 + i, sh[i]);
@@ -60,34 +90,55 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                               const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                              T* __restrict__ y, int64_t B, int HW, int C, int G,
-                                                              float eps, int silu) {
+                                                              T* __restrict__ y, int HW, int C, int G, float eps,
+                                                              int silu, int rows_per_block) {
     constexpr int V = Tr<T>::kVec;
-    const int cg = C / G;
-    const int ppr = C / V;
-    const int64_t total = B * HW * (int64_t)ppr;
+    const int b = blockIdx.y;
+    const int cg = C / G, ppr = C / V;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
     const float inv_n = 1.0f / ((float)HW * (float)cg);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i % ppr);
-        const int64_t row = i / ppr;
-        const int b = (int)(row / HW);
-        const int c0 = p * V;
-        float f[V], ga[V], be[V];
-        unpack<T>(ld16(x + row * C + c0), f);
-        unpack<T>(ld16(gamma + c0), ga);
-        unpack<T>(ld16(beta + c0), be);
+    const T* xb = x + ((int64_t)b * HW) * C;
+    T* yb = y + ((int64_t)b * HW) * C;
+    for (int pc = 0; pc < ppr; pc += 256) {
+        const int cw = min(256, ppr - pc);
+        const int rip = 256 / cw;
+        const int ry = threadIdx.x / cw, p = pc + threadIdx.x % cw;
+        if (ry >= rip) continue;
+        // y = (x - mean) * rstd * gamma + beta  ==  x * sc + sh  with per-channel constants hoisted out of the loop
+        float sc[V], sh[V], ga[V], be[V];
+        unpack<T>(ld16(gamma + p * V), ga);
+        unpack<T>(ld16(beta + p * V), be);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const int g = (c0 + j) / cg;
+            const int g = (p * V + j) / cg;
             const float s1 = stats[((int64_t)b * G + g) * 2], s2 = stats[((int64_t)b * G + g) * 2 + 1];
             const float mean = s1 * inv_n;
             const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
             const float rstd = 1.0f / sqrtf(var + eps);
-            float v = (f[j] - mean) * rstd * ga[j] + be[j];
-            if (silu) v = silu_d(Tr<T>::rnd(v));
-            f[j] = v;
+            sc[j] = rstd * ga[j];
+            sh[j] = be[j] - mean * sc[j];
         }
-        st16(y + row * C + c0, pack<T>(f));
+        const T* xp = xb + (int64_t)p * V;
+        T* yp = yb + (int64_t)p * V;
+        auto one = [&](const uint4& u, int r) {
+            float f[V];
+            unpack<T>(u, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float v = fmaf(f[j], sc[j], sh[j]);
+                if (silu) v = silu_fast(Tr<T>::rnd(v));
+                f[j] = v;
+            }
+            st16(yp + (int64_t)r * C, pack<T>(f));
+        };
+        int r = r0 + ry;
+        for (; r + rip < r1; r += 2 * rip) {
+            const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
+            one(u0, r);
+            one(u1, r + rip);
+        }
+        if (r < r1) one(ld16(xp + (int64_t)r * C), r);
     }
 }
 
@@ -98,19 +149,17 @@ int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y
     SS_REQUIRE(C % G == 0 && C % V == 0, "groupnorm: C=%lld G=%lld unsupported", (long long)C, (long long)G);
     if (B * HW == 0) return SS_OK;
     SS_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), s));
-    // ~256 KiB of activations per block, at least enough blocks to fill the chip
-    int rows_per_block = (int)((256 * 1024) / (C * sizeof(T)));
+    // ~128 KiB of activations per block, at least enough blocks to fill the chip several times
+    int rows_per_block = (int)((128 * 1024) / (C * sizeof(T)));
     if (rows_per_block < 16) rows_per_block = 16;
-    while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 512) rows_per_block /= 2;
+    while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 2048) rows_per_block /= 2;
     if (rows_per_block > HW) rows_per_block = (int)HW;
     dim3 grid((unsigned)cdiv(HW, rows_per_block), (unsigned)B);
     hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), (size_t)G * 2 * sizeof(float), s, (const T*)x, stats,
                        (int)HW, (int)C, (int)G, rows_per_block);
     SS_LAUNCH_CHECK("groupnorm_stats");
-    int64_t blocks = (B * HW * (C / V) + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(groupnorm_apply_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, stats,
-                       (const T*)gamma, (const T*)beta, (T*)y, B, (int)HW, (int)C, (int)G, eps, silu);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<T>, grid, dim3(256), 0, s, (const T*)x, stats, (const T*)gamma,
+                       (const T*)beta, (T*)y, (int)HW, (int)C, (int)G, eps, silu, rows_per_block);
     SS_LAUNCH_CHECK("groupnorm_apply");
     return SS_OK;
 }
