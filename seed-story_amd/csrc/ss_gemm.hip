@@ -53,6 +53,24 @@ template <> struct Mma<f16_t> {
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf-GELU for 16-bit outputs: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, three orders below a bf16 ulp) on the
+// hardware rcp / exp2 — about a third of the VALU work of libm's branchy erff.  The GEGLU epilogue of the UNet's ff1
+// evaluates 42 M of these per launch, serially after the K loop.
+__device__ __forceinline__ float gelu_erf16(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|v|/sqrt2)
+    return 0.5f * v + 0.5f * fabsf(v) * erf_abs;              // 0.5 v (1 + sign(v) erf(|v|/sqrt2))
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float v) {
+    if constexpr (Tr<T>::kVec == 8) return gelu_erf16(v);
+    else return gelu_erf(v);
+}
 
 struct GemmArgs {
     const void* A; const void* W; void* C; const void* bias; const void* residual;
@@ -347,7 +365,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[i][j][r] + bv[r];
-                if (g.epi & SS_EPI_GELU) t = gelu_erf(Tr<T>::rnd(t));
+                if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
                 v[r] = Tr<T>::rnd(t);
                 if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);   // h = conv(x) + temb[:, :, None, None]
             }
@@ -364,7 +382,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 }
             }
             if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
-                const float o0 = v[0] * Tr<T>::rnd(gelu_erf(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_erf(v[3]));
+                const float o0 = v[0] * Tr<T>::rnd(gelu_for<T>(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_for<T>(v[3]));
                 if (full && ((g.ldc & 1) == 0) && (((size_t)g.C & 3) == 0) && Tr<T>::kVec == 8) {
                     float pk[8] = {o0, o1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<uint32_t*>(C + (int64_t)m * g.ldc + (n0 >> 1)) = pack<T>(pk).x;
@@ -679,7 +697,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
 
     issue_tile(0, 0);
     if (ntiles > 1) issue_tile(1, 1);
-    if (ntiles > 1) wait_vmcnt<IA + IW>(); else wait_vmcnt<0>();   // tile 0 landed (tile 1 may still fly)
+    // tile 0 landed (tile 1 may still fly).  CONV: a wave whose 64 lanes are all padding skips that DMA entirely, so
+    // the number of outstanding loads per tile is not a constant there and only a full drain is safe
+    if (ntiles > 1 && !CONV) wait_vmcnt<IA + IW>(); else wait_vmcnt<0>();
     __syncthreads();
     read_phase(0, 0);
     if constexpr (NH > 1) asm volatile("s_nop 7" ::: "memory");   // asm MFMAs are opaque to the hazard recognizer

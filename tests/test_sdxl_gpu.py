@@ -73,13 +73,17 @@ def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
     Ho, Wo = ref.shape[2], ref.shape[3]
     res = synth.normal_like(205, (B, Co, Ho, Wo), 1.0, dtype=dtype)
     _lib.set_tuning("gemm_cfg", cfg)
+    xd, wd_, bd, tvd, rd = nhwc(x).to(DEV), _conv_w(w).to(DEV), b.to(DEV), tv.to(DEV), nhwc(res).to(DEV)
     try:
-        y, ho, wo = ops.conv3x3(nhwc(x).to(DEV), _conv_w(w).to(DEV), B, H, W, stride=stride, upsample=up, bias=b.to(DEV),
-                                rowvec=tv.to(DEV), residual=nhwc(res).to(DEV))
+        ys = [ops.conv3x3(xd, wd_, B, H, W, stride=stride, upsample=up, bias=bd, rowvec=tvd, residual=rd)
+              for _ in range(6)]     # repeated: a staging race (e.g. a miscounted DMA wait) shows up as run-to-run drift
     finally:
         _lib.set_tuning("gemm_cfg", 0)
+    y, ho, wo = ys[0]
     assert (ho, wo) == (Ho, Wo)
     assert rel(nchw(y.cpu(), B, Ho, Wo), ref + tv.float()[:, :, None, None] + res.float()) < 1e-2
+    for other, _, _ in ys[1:]:
+        assert torch.equal(other, y)
 
 
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 5, 7, 32), (1, 320, 16, 16, 32), (2, 128, 33, 9, 32), (1, 1920, 4, 4, 32)])
