@@ -307,29 +307,42 @@ def main():
         for b in range(SPG):
             eng.select(b).set_lengths(343, 343)
         prof = eng.profile_decode(8)
-        # dominant kernel: ss::gemv_kernel<bf16,8,2> (65 launches/token: qkv, o, gate|up x32 + lm_head)
-        per_launch_bytes = prof["gemv_bytes"] / prof["gemv_launches"]
-        per_launch_ms = prof["gemv_ms"] / prof["gemv_launches"]
+        # dominant kernel = the decode weight-streaming GEMV.  With <= 2 slots per sweep the K=hidden projections
+        # (qkv, o, gate|up per layer + lm_head: 97 launches/token) are ss::gemv_kernel<bf16,8,2,NB> and the down
+        # projection a different symbol; with 3-4 slots every projection runs ss::gemv_ldsx_kernel<bf16,2,NB>
+        # (129 launches/token), so the launch average is taken over all of them.
+        if SPG <= 2:
+            kern = "gemv_kernel<bf16_t,8,2,%d>" % SPG
+            n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
+        else:
+            kern = "gemv_ldsx_kernel<bf16_t,2,%d>" % SPG
+            n_launch = prof["gemv_launches"] + prof["gemv_down_launches"]
+            tot_bytes = prof["gemv_bytes"] + prof["gemv_down_bytes"]
+            tot_ms = prof["gemv_ms"] + prof["gemv_down_ms"]
+        per_launch_bytes = tot_bytes / n_launch
+        per_launch_ms = tot_ms / n_launch
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         down = prof["gemv_down_bytes"] / (prof["gemv_down_ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
-        if os.path.exists(pmc):      # HBM bytes per launch from the separate rocprofv3 --pmc pass of this command
+        if os.path.exists(pmc):      # HBM bytes per launch from the separate rocprofv3 --pmc passes of this command
             try:
-                traffic = json.load(open(pmc)).get("gemv_kernel_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))      # counters were collected at pj["stories_per_gpu"] slots per sweep
+                if pj.get("stories_per_gpu") == SPG:
+                    traffic = pj.get("gemv_hbm_traffic", {}).get(kern, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": ("ss::gemv_kernel<bf16_t,8,2,%d>" % SPG) if SPG <= 2 else ("ss::gemv_ldsx_kernel<bf16_t,2,%d>" % SPG),
-                "slots_per_sweep": SPG,
-                "launches_per_token": prof["gemv_launches"], "bytes_per_launch": round(per_launch_bytes),
+                "kernel": "ss::" + kern, "slots_per_sweep": SPG,
+                "launches_per_token": n_launch, "bytes_per_launch": round(per_launch_bytes),
                 "avg_launch_us": round(per_launch_ms * 1e3, 3),
-                "also": {"gemv_ldsx_kernel(down proj) GB/s": round(down, 1),
+                "also": {"down projection GB/s": round(down, 1),
                          "all_gemv GB/s per token": round((prof["gemv_bytes"] + prof["gemv_down_bytes"]) /
                                                           ((prof["gemv_ms"] + prof["gemv_down_ms"]) * 1e-3) / 1e9, 1),
                          "token_ms_eager": round(prof["token_ms"], 4), "attn_ms": round(prof["attn_ms"], 4),
-                         "misc_ms": round(prof["misc_ms"], 4)}}
+                         "misc_ms": round(prof["misc_ms"], 4),
+                         "weight_bytes_per_generated_token_per_story": round(13.215e9 / SPG)}}
     if rank == 0 and adapter is not None:
         # MFMA-bound half: one SDXL-base UNet forward (batch 2S = CFG pairs of the S resident stories, 128x128
         # latents), HIP events on the stream
