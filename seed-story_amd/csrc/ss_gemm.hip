@@ -81,7 +81,30 @@ struct GemmArgs {
     const void* rowvec; int rows_per_batch; int64_t rowvec_ld;
     // implicit-GEMM 3x3 convolution over an NHWC tensor (A = [B, H, W, Cin]); K = 9 * Cin
     int conv_H, conv_W, conv_Cin, conv_stride, conv_up, conv_Ho, conv_Wo;
+    int swz;   // XCD-aware tile order (0 = row-major block ids)
 };
+
+// blockIdx -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and every XCD
+// has a private 4 MB L2, so with row-major tile ids the blocks that share an A row-tile (or a W column-tile) land on
+// eight different L2s and nothing is reused below the Infinity Cache: a K=5120 GEMM then pulls > 5 TB/s through
+// MALL/HBM and is memory-bound, not MFMA-bound.  Remap: (1) XCD k owns a CONTIGUOUS range of logical tile ids,
+// (2) logical ids walk groups of GM m-tiles n-major, so the ~32-64 blocks resident on one XCD form a GM x (32/GM)
+// patch of the output that shares GM A-tiles and a few W-tiles through that XCD's L2.
+__device__ __forceinline__ void xcd_tile(int swz, int MT, int NT, int& mt, int& nt) {
+    if (!swz) { mt = blockIdx.y; nt = blockIdx.x; return; }
+    const int total = MT * NT;
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int base = total >> 3, rem = total & 7;
+    const int L = xcd * base + (xcd < rem ? xcd : rem) + j;
+    const int GM = swz;
+    const int per_group = GM * NT;
+    const int gidx = L / per_group, r = L - gidx * per_group;
+    const int m0 = gidx * GM;
+    const int gm = (MT - m0) < GM ? (MT - m0) : GM;
+    nt = r / gm;
+    mt = m0 + r - nt * gm;
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int KT, bool CONV>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
@@ -423,7 +446,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmArgs 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR) for the DMA bases
     const int wm = wid / WN, wn = wid % WN;
     const int l15 = lane & 15, grp = lane >> 4;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    int mt_, nt_;
+    xcd_tile(g.swz, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, mt_, nt_);
+    const int m_blk = mt_ * BM, n_blk = nt_ * BN;
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
     const int K = g.K, M = g.M, N = g.N;
@@ -578,7 +603,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int l15 = lane & 15, grp = lane >> 4;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    int mt_, nt_;
+    xcd_tile(g.swz, (g.M + BM - 1) / BM, (g.N + BN - 1) / BN, mt_, nt_);
+    const int m_blk = mt_ * BM, n_blk = nt_ * BN;
     const int M = g.M, N = g.N;
     const int ntiles = g.K / 64;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void_t*)smem_raw);
@@ -831,8 +858,11 @@ static std::map<TuneKey, int>& tune_cache() {
     return m;
 }
 
+// A tuned entry is (tile config, XCD group size): the tile order's effect is as shape-dependent as the tile's
+// (tools/gpu_diag.py gemm_unet: -13 % ... +28 %).  Candidates are timed COLD — a 320 MB scratch fill between runs
+// evicts the operands from L2 / Infinity Cache — because in the pipeline every weight is touched once per forward.
 template <typename T>
-static int autotuned_cfg(const GemmArgs& g0, hipStream_t s) {
+static int autotuned_cfg(GemmArgs& g0, hipStream_t s) {
     const int fallback = pick_cfg(g0.M, g0.N);
     if (Tr<T>::kVec != 8 || g0.M <= 128 || tuning_get("gemm_cfg", 0) || !tuning_get("gemm_autotune", 1)) return fallback;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -841,34 +871,46 @@ static int autotuned_cfg(const GemmArgs& g0, hipStream_t s) {
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = tune_cache().find(key);
-        if (it != tune_cache().end()) return it->second;
+        if (it != tune_cache().end()) { g0.swz = it->second / 100; return it->second % 100; }
     }
+    static void* flush = nullptr;
+    const size_t flush_bytes = (size_t)320 << 20;
+    if (!flush && hipMalloc(&flush, flush_bytes) != hipSuccess) { flush = nullptr; return fallback; }
     void* scratch = nullptr;
     if (hipMalloc(&scratch, (size_t)g0.M * g0.N * sizeof(T)) != hipSuccess) return fallback;
     GemmArgs g = g0;
     g.C = scratch; g.ldc = g0.N; g.residual = nullptr; g.epi &= ~SS_EPI_RESIDUAL;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    // 8/15/10 = double-buffered DMA kernels (128x128, 128x64, 64x64), 20/21/23 = software-pipelined DMA kernels
-    // (128x128, 128x64, 256x128); the pipelined ones win every conv (+20-40 %) and the widest plain GEMMs
-    // 24 = 256x256 with 128x64 wave tiles (accumulators pinned): best on long-K problems (3x3 convs, ff2)
+    // 8/15/10 = double-buffered DMA kernels (128x128, 128x64, 64x64); 20/21/23 = software-pipelined DMA kernels
+    // (128x128, 128x64, 256x128); 24 = 256x256 with 128x64 wave tiles (accumulators pinned)
     const int cands[7] = {8, 15, 10, 20, 21, 23, 24};
-    int best = fallback;
+    const int swzs[3] = {0, 4, 8};
+    int best = fallback, best_swz = g0.swz;
     float best_ms = 1e30f;
     for (int c : cands) {
-        if (gemm_dispatch_cfg<T>(c, g, s) != SS_OK) continue;   // warm-up (also faults pages in)
-        hipEventRecord(e0, s);
-        for (int r = 0; r < 3; ++r) gemm_dispatch_cfg<T>(c, g, s);
-        hipEventRecord(e1, s);
-        if (hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = c; }
+        for (int z : swzs) {
+            g.swz = z;
+            if (gemm_dispatch_cfg<T>(c, g, s) != SS_OK) continue;   // warm-up (also faults pages in)
+            float tot = 0.f;
+            bool ok = true;
+            for (int r = 0; r < 2 && ok; ++r) {
+                hipMemsetAsync(flush, r, flush_bytes, s);
+                hipEventRecord(e0, s);
+                gemm_dispatch_cfg<T>(c, g, s);
+                hipEventRecord(e1, s);
+                ok = hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0.f;
+                if (ok) { hipEventElapsedTime(&ms, e0, e1); tot += ms; }
+            }
+            if (ok && tot < best_ms) { best_ms = tot; best = c; best_swz = z; }
+        }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(scratch);
     std::lock_guard<std::mutex> lk(g_tune_mutex);
-    tune_cache()[key] = best;
+    tune_cache()[key] = best + 100 * best_swz;
+    g0.swz = best_swz;
     return best;
 }
 
@@ -889,6 +931,7 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.epi = epi;
     g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
+    g.swz = tuning_get("gemm_xcd_swizzle", 8);
     return gemm_dispatch_cfg<T>(autotuned_cfg<T>(g, s), g, s);
 }
 
@@ -908,6 +951,7 @@ int conv3x3_launch(const void* x, const void* w, void* y, int64_t B, int64_t H, 
     g.M = (int)(B * Ho * Wo); g.N = (int)Cout; g.K = (int)(9 * Cin);
     g.lda = 0; g.ldw = 9 * Cin; g.ldc = Cout; g.ldr = Cout; g.epi = epi;
     g.rowvec = rowvec; g.rows_per_batch = (int)(Ho * Wo); g.rowvec_ld = rowvec_ld > 0 ? rowvec_ld : Cout;
+    g.swz = tuning_get("gemm_xcd_swizzle", 8);
     g.conv_H = (int)H; g.conv_W = (int)Wd; g.conv_Cin = (int)Cin; g.conv_stride = (int)stride; g.conv_up = (int)up;
     g.conv_Ho = (int)Ho; g.conv_Wo = (int)Wo;
     if (g.M == 0) return SS_OK;

@@ -238,34 +238,49 @@ def bench_decode():
 
 
 def bench_gemm_unet():
+    """UNet GEMM / conv shapes at batch 8: tile configs x XCD-aware tile order (gemm_xcd_swizzle = group size, 0 = off).
+    Operands rotate over several copies so that the Infinity Cache cannot hold them between calls (in the UNet every
+    weight is touched once per forward)."""
     res = []
     shapes = [(8192, 3840, 1280), (8192, 1280, 1280), (8192, 10240, 1280), (8192, 1280, 5120), (32768, 1920, 640),
-              (32768, 640, 640), (32768, 5120, 640), (32768, 640, 2560), (2048, 3840, 1280), (2048, 1280, 1280),
-              (2048, 10240, 1280), (2048, 1280, 5120), (4096, 4096, 4096), (1024, 4992, 1664), (343, 12288, 4096)]
+              (32768, 640, 640), (32768, 5120, 640), (32768, 640, 2560), (2048, 10240, 1280), (2048, 1280, 5120),
+              (4096, 4096, 4096)]
     for M, N, K in shapes:
-        a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
-        w = torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02
+        ncopy = 4
+        a = [torch.randn(M, K, device=DEV, dtype=torch.bfloat16) for _ in range(ncopy)]
+        w = [torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02 for _ in range(ncopy)]
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         row = dict(M=M, N=N, K=K)
-        for cfg in (8, 15, 20, 21, 23, 24, 25):
-            _lib.set_tuning("gemm_cfg", cfg)
-            ms = timeit(lambda: ops.gemm(a, w, out=out), iters=10)
-            row["cfg%d" % cfg] = round(2.0 * M * N * K / ms / 1e9)
+        for cfg in (8, 21, 23, 24):
+            for swz in (0, 4, 8, 16):
+                _lib.set_tuning("gemm_cfg", cfg)
+                _lib.set_tuning("gemm_xcd_swizzle", swz)
+                st = {"i": 0}
+
+                def f():
+                    st["i"] += 1
+                    ops.gemm(a[st["i"] % ncopy], w[st["i"] % ncopy], out=out)
+                ms = timeit(f, iters=12)
+                row["c%d_s%d" % (cfg, swz)] = round(2.0 * M * N * K / ms / 1e9)
         res.append(row)
         print(row, flush=True)
+        del a, w
     convs = [(8, 128, 128, 320, 320), (8, 64, 64, 640, 640), (8, 32, 32, 1280, 1280), (8, 32, 32, 2560, 1280),
-             (8, 64, 64, 1920, 640), (8, 128, 128, 960, 320), (1, 1024, 1024, 128, 128), (1, 512, 512, 256, 256)]
+             (8, 64, 64, 1920, 640), (1, 1024, 1024, 128, 128)]
     for B, H, W, Ci, Co in convs:
         x = torch.randn(B * H * W, Ci, device=DEV, dtype=torch.bfloat16)
         w = torch.randn(Co, 9 * Ci, device=DEV, dtype=torch.bfloat16) * 0.02
         row = dict(conv=(B, H, W, Ci, Co))
-        for cfg in (8, 15, 20, 21, 23, 24, 25):
-            _lib.set_tuning("gemm_cfg", cfg)
-            ms = timeit(lambda: ops.conv3x3(x, w, B, H, W), iters=5)
-            row["cfg%d" % cfg] = round(2.0 * B * H * W * Co * 9 * Ci / ms / 1e9)
+        for cfg in (20, 23, 24):
+            for swz in (0, 4, 8, 16):
+                _lib.set_tuning("gemm_cfg", cfg)
+                _lib.set_tuning("gemm_xcd_swizzle", swz)
+                ms = timeit(lambda: ops.conv3x3(x, w, B, H, W), iters=5)
+                row["c%d_s%d" % (cfg, swz)] = round(2.0 * B * H * W * Co * 9 * Ci / ms / 1e9)
         res.append(row)
         print(row, flush=True)
     _lib.set_tuning("gemm_cfg", 0)
+    _lib.set_tuning("gemm_xcd_swizzle", 8)
     OUT["gemm_unet"] = res
 
 
