@@ -360,11 +360,33 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         flops = UB * 6.747e12                                  # 3.3735 TMAC per sample per forward
+        # the single dominant MFMA kernel of the forward: the GEGLU ff1 projection of the 1280-wide transformer blocks
+        # (60 launches per forward, ~17 % of its time): [UB*1024, 1280] x [10240, 1280]^T with the value*gelu(gate)
+        # epilogue.  Timed over rotating weight copies (each UNet weight is touched once per forward).
+        from seedstory import ops as _ops
+        Mg, Ng, Kg = UB * 1024, 10240, 1280
+        ag = torch.randn(Mg, Kg, device=device, dtype=dtype)
+        wg = [torch.randn(Ng, Kg, device=device, dtype=dtype) * 0.02 for _ in range(4)]
+        bg = torch.zeros(Ng, device=device, dtype=dtype)
+        for i in range(2):
+            _ops.gemm_geglu(ag, wg[i], bg)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for i in range(12):
+            _ops.gemm_geglu(ag, wg[i % 4], bg)
+        g1.record()
+        torch.cuda.synchronize()
+        gemm_us = g0.elapsed_time(g1) / 12 * 1e3
+        gemm_tf = 2.0 * Mg * Ng * Kg / (gemm_us * 1e-6) / 1e12
+        del ag, wg
         roof_mllm = roof
         roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": None,
-                "kernel": "SDXL UNet forward (ss::gemm_kernel<bf16,*> incl. implicit-GEMM conv3x3 + ss::flash_attn_kernel<bf16,64>)",
+                "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel / gemm_glds_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn2_kernel<bf16,64>, norms)",
                 "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
+                "dominant_kernel": {"kernel": "ss::gemm_sp_kernel / gemm_glds_kernel (autotuned tile) + GEGLU epilogue",
+                                    "shape_MNK": [Mg, Ng, Kg], "avg_launch_us": round(gemm_us, 1),
+                                    "achieved": round(gemm_tf, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / 2500.0, 4)},
                 "note": "a round is 30 UNet forwards of batch %d (MFMA-bound) + 115 decode tokens for %d slots (HBM-bound): see mllm_decode_gemv" % (UB, SPG),
                 "mllm_decode_gemv": roof_mllm}
     cpu = None

@@ -319,13 +319,26 @@ void flash_attn2_kernel(const AttnArgs a) {
         }
     };
 
-    if (ntiles > 0) issue_tile(0, 0);
+    // 3-deep K/V ring: tiles t+1 and t+2 are in flight while tile t is consumed.  One tile of prefetch distance
+    // (~0.6 us of work at head_dim 64) is shorter than a DMA round trip, so a 2-deep ring stalled at every barrier.
+    constexpr int NSTAGE = HD <= 64 ? 3 : 2;   // head_dim 128 tiles are twice as large: 2 stages keep 2 blocks per CU
+    constexpr int DPT = 2 * IPW;               // DMA instructions per tile per wave (K and V)
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+        if (st < ntiles) issue_tile(st, st);
+    int stage = 0;
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
-        const char* Kb = smem_raw + (t & 1) * 2 * TILE_B;
+        if (NSTAGE == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");   // tile t landed, t+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // ... for every wave; the stage of tile t-1 is drained
+        if (t + NSTAGE - 1 < ntiles) {
+            int ns = stage + NSTAGE - 1;
+            if (ns >= NSTAGE) ns -= NSTAGE;
+            issue_tile(t + NSTAGE - 1, ns);
+        }
+        const char* Kb = smem_raw + stage * 2 * TILE_B;
         const char* Vb = Kb + TILE_B;
+        if (++stage == NSTAGE) stage = 0;
         const int t0 = t * kBKV;
 
         // ---- S^T = K Q^T for both 16-row query blocks ---------------------------------------------
@@ -441,7 +454,7 @@ void flash_attn2_kernel(const AttnArgs a) {
 
 template <typename T, int HD>
 static int flash2_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
-    const size_t lds = (size_t)2 * 2 * kBKV * HD * 2;
+    const size_t lds = (size_t)(HD <= 64 ? 3 : 2) * 2 * kBKV * HD * 2;   // ring of (K, V) tiles
     dim3 grid((unsigned)cdiv(a.q_len, 128), (unsigned)(batch * a.n_heads));
     hipLaunchKernelGGL((flash_attn2_kernel<T, HD>), grid, dim3(256), lds, s, a);
     SS_LAUNCH_CHECK("flash_attn2");
