@@ -690,6 +690,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
     // Phase p multiplies A set (p & 1) with W set (ks & 1); the operands of phase p+1 are read while the MFMAs
     // of phase p run.  NH = 2 halves the fragment registers of a 128-row wave tile (64 instead of 96 VGPRs).
     constexpr int FMH = FM / NH, P = 2 * NH;
+    constexpr bool PIN = true;   // accumulate-in-place asm MFMAs: the allocator otherwise shuttles accumulators through copies
     static_assert(FM % NH == 0, "A fragments must split evenly");
     uint4 fa[2][FMH], fw[2][FN];
     auto read_phase = [&](int buf, int p) {   // operands of phase p of the tile in buffer `buf`
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
             for (int j = 0; j < FMH; ++j) {
                 // 128-row wave tiles (NH = 2): the allocator otherwise shuttles the 128 accumulator registers
                 // through copies around every MFMA; the asm form pins accumulate-in-place
-                if constexpr (NH > 1) Mma<T>::run_inplace(fw[ks & 1][i], fa[p & 1][j], acc[i][h * FMH + j]);
+                if constexpr (PIN) Mma<T>::run_inplace(fw[ks & 1][i], fa[p & 1][j], acc[i][h * FMH + j]);
                 else acc[i][h * FMH + j] = Mma<T>::run(fw[ks & 1][i], fa[p & 1][j], acc[i][h * FMH + j]);
             }
     };
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
     if (ntiles > 1 && !CONV) wait_vmcnt<IA + IW>(); else wait_vmcnt<0>();
     __syncthreads();
     read_phase(0, 0);
-    if constexpr (NH > 1) asm volatile("s_nop 7" ::: "memory");   // asm MFMAs are opaque to the hazard recognizer
+    if constexpr (PIN) asm volatile("s_nop 7" ::: "memory");   // asm MFMAs are opaque to the hazard recognizer
     // one K tile: phases 0 .. P-2 each prefetch their successor; before the LAST phase's MFMAs comes the tile's one
     // barrier (tile t+1 landed, buffer of tile t drained), the DMA of tile t+2 and the prefetch of tile t+1's phase 0.
     // (sched_barrier pins the phase order: left alone, the scheduler sinks the MFMAs behind the barrier and the
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_sp_kernel(const GemmArgs g)
         step(t + 1, 1);
     }
     if (t < ntiles) step(t, 0);
-    if constexpr (NH > 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results settle before VALU reads them
+    if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results settle before VALU reads them
 
     gemm_epilogue<T, FM, FN>(g, acc, m_blk + wm * TM, n_blk + wn * TN, l15, grp);
 }
@@ -829,6 +830,9 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
         case 23: return gemm_sp_launch_cfg<T, 256, 128, 4, 2>(g, s);
         case 24: return gemm_sp_launch_cfg<T, 256, 256, 2, 4, 2>(g, s);   // 8 waves, 128x64 per wave, A in halves
         case 25: return gemm_sp_launch_cfg<T, 256, 128, 2, 2, 2>(g, s);   // 4 waves, 128x64 per wave
+        // 160-wide tiles: every SDXL channel count (640 ... 10240) is a multiple of 160, and [8192 x 1280] outputs
+        // are exactly 512 tiles of 128x160 = one full wave of 2 blocks per CU (128x128 leaves the second wave 3/4 empty)
+        case 26: return gemm_sp_launch_cfg<T, 128, 160, 2, 2>(g, s);
         default: return gemm_launch_cfg<T, 128, 32, 4, 1>(g, s);
     }
 }
@@ -883,8 +887,8 @@ static int autotuned_cfg(GemmArgs& g0, hipStream_t s) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     // 8/15/10 = double-buffered DMA kernels (128x128, 128x64, 64x64); 20/21/23 = software-pipelined DMA kernels
-    // (128x128, 128x64, 256x128); 24 = 256x256 with 128x64 wave tiles (accumulators pinned)
-    const int cands[7] = {8, 15, 10, 20, 21, 23, 24};
+    // (128x128, 128x64, 256x128); 24 = 256x256 with 128x64 wave tiles (accumulators pinned); 26 = 128x160
+    const int cands[8] = {8, 15, 10, 20, 21, 23, 24, 26};
     const int swzs[3] = {0, 4, 8};
     int best = fallback, best_swz = g0.swz;
     float best_ms = 1e30f;
