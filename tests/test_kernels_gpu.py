@@ -205,7 +205,7 @@ def test_gemm_every_tile_config(ops, cfg):
     assert rel(y, a.float() @ w.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 25, 26, 28, 29])
 @pytest.mark.parametrize("M,N,K", [(200, 300, 512), (1024, 640, 1280), (333, 1000, 64), (4096, 256, 2560), (130, 72, 192)])
 def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
     """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-23 software-pipelined) on ragged and

@@ -55,7 +55,7 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
-@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 25, 26, 28, 29])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
 def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):

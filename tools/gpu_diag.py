@@ -251,7 +251,7 @@ def bench_gemm_unet():
         w = [torch.randn(N, K, device=DEV, dtype=torch.bfloat16) * 0.02 for _ in range(ncopy)]
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         row = dict(M=M, N=N, K=K)
-        for cfg in (8, 21, 24, 26):
+        for cfg in (24, 26, 28, 29):
             for swz in (0, 8):
                 _lib.set_tuning("gemm_cfg", cfg)
                 _lib.set_tuning("gemm_xcd_swizzle", swz)
@@ -271,7 +271,7 @@ def bench_gemm_unet():
         x = torch.randn(B * H * W, Ci, device=DEV, dtype=torch.bfloat16)
         w = torch.randn(Co, 9 * Ci, device=DEV, dtype=torch.bfloat16) * 0.02
         row = dict(conv=(B, H, W, Ci, Co))
-        for cfg in (20, 24, 26):
+        for cfg in (26, 28, 29):
             for swz in (0, 8):
                 _lib.set_tuning("gemm_cfg", cfg)
                 _lib.set_tuning("gemm_xcd_swizzle", swz)
