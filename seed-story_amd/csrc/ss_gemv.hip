@@ -249,49 +249,56 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(const GemvArgs a) {
         }
     };
 
-    float rstd[NB];
-    if (a.norm_w) {
-        // the statistic is computed per wave with the register kernel's summation order (lane-strided
-        // packs, then the wave reduction), so a row normalises to the same bits at every batch width
+    // ---- stage the NB activation rows in LDS: ONE global read of x per block ------------------------------------
+    // (every block needs all of x; at NB = 4 the old per-wave statistic + second read pulled more bytes of x through
+    // L2 than the launch streams weights from HBM)
+    float ssq[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const T* xg = (const T*)a.x + (int64_t)b * a.x_ld;
-            float ssq = 0.f;
-#pragma unroll 4
-            for (int p = lane; p < npack; p += 64) {
-                float f[V];
-                unpack<T>(ld16(xg + (int64_t)p * V), f);
-#pragma unroll
-                for (int j = 0; j < V; ++j) ssq = fmaf(f[j], f[j], ssq);
-            }
-            ssq = wave_sum(ssq);
-            rstd[b] = 1.0f / sqrtf(ssq / (float)K + a.eps);
-        }
-    }
-    // staging: per pack index, the NB rows' packs and the (shared) norm weight pack are requested together
-    // and two pack indices are in flight per thread, so the L2 round trips overlap instead of chaining
+    for (int b = 0; b < NB; ++b) ssq[b] = 0.f;
 #pragma unroll 2
     for (int p = threadIdx.x; p < npack_pad; p += blockDim.x) {
-        uint4 v[NB], gwv = make_uint4(0, 0, 0, 0);
         const bool ok = p < npack;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            v[b] = ok ? ld16((const T*)a.x + (int64_t)b * a.x_ld + (int64_t)p * V) : make_uint4(0, 0, 0, 0);
-        if (a.norm_w && ok) gwv = ld16((const T*)a.norm_w + (int64_t)p * V);
-        if (a.norm_w) {
+        for (int b = 0; b < NB; ++b) {
+            const uint4 v = ok ? ld16((const T*)a.x + (int64_t)b * a.x_ld + (int64_t)p * V) : make_uint4(0, 0, 0, 0);
+            if (a.norm_w) {
+                float f[V];
+                unpack<T>(v, f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) ssq[b] = fmaf(f[j], f[j], ssq[b]);
+            }
+            xs[(size_t)b * npack_pad + p] = v;
+        }
+    }
+    if (a.norm_w) {
+        // fused RMSNorm: block-wide statistic in a fixed order (lane tree, then waves 0..n-1), then each thread
+        // normalises its own packs in place
+        __shared__ float red[NB][16];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float w = wave_sum(ssq[b]);
+            if (lane == 0) red[b][threadIdx.x >> 6] = w;
+        }
+        __syncthreads();
+        float rstd[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float t = 0.f;
+            for (int w = 0; w < wpb; ++w) t += red[b][w];
+            rstd[b] = 1.0f / sqrtf(t / (float)K + a.eps);
+        }
+        for (int p = threadIdx.x; p < npack; p += blockDim.x) {
             float gw[V];
-            unpack<T>(gwv, gw);
+            unpack<T>(ld16((const T*)a.norm_w + (int64_t)p * V), gw);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float f[V];
-                unpack<T>(v[b], f);
+                unpack<T>(xs[(size_t)b * npack_pad + p], f);
 #pragma unroll
                 for (int j = 0; j < V; ++j) f[j] = gw[j] * Tr<T>::rnd(f[j] * rstd[b]);
-                v[b] = pack<T>(f);
+                xs[(size_t)b * npack_pad + p] = pack<T>(f);
             }
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) xs[(size_t)b * npack_pad + p] = v[b];
     }
     __syncthreads();
 
@@ -351,10 +358,21 @@ static int gemv_launch_nb(const GemvArgs& a, int nit, int64_t waves, hipStream_t
     }
     const size_t lds = (size_t)NB * cdiv(a.K / V, 512) * 512 * 16;
     SS_REQUIRE(lds <= 152 * 1024, "gemv: K=%d x batch %d too large for LDS staging", a.K, NB);
-    // keep >= 12 waves per CU resident: small LDS footprints run several 256-thread blocks per CU,
-    // large ones one 1024-thread block
-    const int threads = lds <= 36 * 1024 ? 256 : lds <= 72 * 1024 ? 512 : 1024;
-    const int blocks = blocks_for(threads / 64);
+    int threads, blocks;
+    if (NB == 1) {
+        // batch 1 (the reference configuration): several 256-thread blocks per CU, ~2.5k waves (measured optimum)
+        threads = lds <= 36 * 1024 ? 256 : lds <= 72 * 1024 ? 512 : 1024;
+        blocks = blocks_for(threads / 64);
+    } else {
+        // every block stages all NB rows of x, so blocks are fat and their count is a whole number per CU
+        // (no CU ends up with one block more than its neighbour): 2 x 512 threads per CU, or 1 x 1024 when the
+        // staged activations exceed half the LDS
+        const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+        threads = per_cu == 2 ? 512 : 1024;
+        blocks = 256 * per_cu;
+        const int64_t max_b = (waves * 2 + threads / 64 - 1) / (threads / 64);   // keep >= ~2 row groups per wave
+        if (blocks > max_b) blocks = (int)(max_b < 1 ? 1 : max_b);
+    }
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)gemv_ldsx_kernel<T, 2, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
