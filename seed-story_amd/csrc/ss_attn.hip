@@ -691,8 +691,11 @@ __global__ void attn_combine_kernel(const float* __restrict__ part, T* __restric
     Tr<T>::st(out + (int64_t)h * hd + d, o / l);
 }
 
-static inline int decode_nsplit() {
-    const int n = tuning_get("attn_decode_nsplit", 16);
+// KV splits per (head, slot): 16 at one slot (512 blocks of ~25 keys at S = 400 — enough to fill the chip, measured
+// optimum), fewer when several story slots already multiply the block count (4 slots: 4 splits, -6 % token time)
+static inline int decode_nsplit(int nb) {
+    int n = tuning_get("attn_decode_nsplit", 0);
+    if (n <= 0) n = 16 / (nb < 1 ? 1 : nb);
     return n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : 32;
 }
 
@@ -702,7 +705,7 @@ int attn_decode_launch(const DecodeArgs& a0, void* out, int64_t n_heads, int64_t
     SS_REQUIRE(hd % V == 0 && 256 % (hd / V) == 0 && 64 % (hd / V) == 0 && hd <= 256,
                "attn_decode: head_dim %lld unsupported", (long long)hd);
     DecodeArgs a = a0;
-    a.nsplit = decode_nsplit();
+    a.nsplit = decode_nsplit(a.nb);
     a.scale = 1.0f / sqrtf((float)hd);
     const int NKG = 256 / (int)(hd / V);
     const size_t lds = (size_t)NKG * (hd + 2) * sizeof(float);

@@ -101,7 +101,7 @@ def bench_attn():
             ms = timeit(lambda: ops.attn_decode(q, kc, vc, n), iters=20)
             res.append(dict(decode_kv=kv, nsplit=ns, ms=round(ms, 4), GBps=round(2 * 32 * kv * 128 * 2 / ms / 1e6, 1)))
             print(res[-1], flush=True)
-    _lib.set_tuning("attn_decode_nsplit", 8)
+    _lib.set_tuning("attn_decode_nsplit", 0)
     OUT["attn"] = res
 
 
@@ -179,6 +179,31 @@ def bench_slots():
         del eng
         torch.cuda.empty_cache()
     OUT["slots"] = res
+
+
+def bench_nsplit():
+    """Decode attention split count at 4 story slots (graph replays)."""
+    res = {}
+    for ns in (4, 8, 16, 32):
+        _lib.set_tuning("attn_decode_nsplit", ns)
+        eng = make_7b_engine(n_seq=4)
+        S = 400
+        for b in range(4):
+            eng.select(b).prefill(torch.randn(S, 4096, device=DEV, dtype=torch.bfloat16) * 0.02)
+        forced = [torch.randint(3, 32000, (115,)).tolist() for _ in range(4)]
+        eng.generate_batch(8, [5] * 4, [f[:8] for f in forced])
+        for b in range(4):
+            eng.select(b).set_lengths(S, S)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ns_out = eng.generate_batch(115, [5] * 4, forced)
+        torch.cuda.synchronize()
+        res["nsplit%d_tok_ms" % ns] = round((time.perf_counter() - t0) * 1e3 / ns_out[0], 4)
+        print(ns, res, flush=True)
+        del eng
+        torch.cuda.empty_cache()
+    _lib.set_tuning("attn_decode_nsplit", 0)
+    OUT["nsplit"] = res
 
 
 def bench_decode():
@@ -328,7 +353,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for w in which:
         try:
-            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode, "sdxl": bench_sdxl, "slots": bench_slots, "gemm_unet": bench_gemm_unet}[w]()
+            {"gemv": bench_gemv, "gemm": bench_gemm, "attn": bench_attn, "decode": bench_decode, "sdxl": bench_sdxl, "slots": bench_slots, "nsplit": bench_nsplit, "gemm_unet": bench_gemm_unet}[w]()
         except Exception as ex:  # keep going: one broken kernel must not hide the other numbers
             import traceback
             traceback.print_exc()
