@@ -352,6 +352,15 @@ int ss_euler_cfg_step(void* x, const void* eps, int64_t n, float guidance, float
 /* VAE output NHWC [pixels, cpad] -> uint8 HWC: round(clamp(x/2 + 0.5, 0, 1) * 255). */
 int ss_image_to_u8(const void* in, void* out_u8, int64_t pixels, int64_t cpad, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Diagnostics
+ * ------------------------------------------------------------------------------------- */
+/* One wave executes ds_read_b64_tr_b16 with per-lane LDS offsets lane_off[64] (int32, in 16-bit
+ * elements) over an 8 KB LDS image copied from src (4096 u16), and writes each lane's four 16-bit
+ * results to dst[64*4].
+ * Documents the transposed-read lane mapping flash_attn2_kernel relies on (tools/tr_probe.py). */
+int ss_debug_tr_probe(const void* src, void* dst, const void* lane_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ss_euler_scale_dup": (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
     "ss_euler_cfg_step": (C.c_int, [vp, vp, i64, f32, f32, f32, C.c_int, vp]),
     "ss_image_to_u8": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),
+    "ss_debug_tr_probe": (C.c_int, [vp, vp, vp, vp]),
 }
 
 _lib = None
