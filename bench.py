@@ -111,10 +111,10 @@ class Story:
         return cap + IMG_IDS + [EOS]
 
 
-def run_round(sts, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
-    """One multimodal step of every resident story (slot b of the engine = story sts[b]); all stories of
-    a round are at the same step index.  With one story this is exactly one ``agent.generate`` +
-    ``adapter.generate`` of gen_george.py."""
+def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
+    """The MLLM half of one multimodal step of every resident story (slot b of the engine = story sts[b]; all
+    stories of a round are at the same step index): ``agent.generate`` of gen_george.py:189/257.  Advances the
+    stories' context (ids, image features) and returns img_gen_feat [S,256,4096]."""
     from seedstory import ops
     dev = sts[0].device
     for b, st in enumerate(sts):
@@ -144,15 +144,27 @@ def run_round(sts, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
     e = CAPTION + 65                                                      # index of </img> in the generated ids
     feats = torch.stack([eng.select(b).hidden_rows[e - 64:e] for b in range(len(sts))]).contiguous()   # models.py:197
     img_gen_feat = rout(feats)                                            # models.py:205  [S,256,4096]
-    if adapter is not None:                                               # gen_george.py:210 (30 steps: BASELINE)
-        imgs = adapter.generate(image_embeds=img_gen_feat, num_inference_steps=steps, output_type="pt")
-        imgs = imgs.unsqueeze(0) if len(sts) == 1 else imgs
     for b, st in enumerate(sts):
-        if adapter is not None:
-            st.last_image = imgs[b]
         st.image_embeds = torch.cat([st.image_embeds, img_gen_feat[b:b + 1]], dim=0)   # gen_george.py:224
         st.ids = st.ids + forced[b][:CAPTION] + IMG_IDS                   # prompt + text + image_tokens (:231)
         st.step += 1
+    return img_gen_feat
+
+
+def sdxl_part(sts, adapter, img_gen_feat, steps):
+    """The de-tokenizer half: ``adapter.generate`` (gen_george.py:210) for the S images of the round."""
+    imgs = adapter.generate(image_embeds=img_gen_feat, num_inference_steps=steps, output_type="pt")
+    imgs = imgs.unsqueeze(0) if len(sts) == 1 else imgs
+    for b, st in enumerate(sts):
+        st.last_image = imgs[b]
+    return imgs
+
+
+def run_round(sts, eng, rin, rout, vit, kv_reuse, adapter=None, steps=30):
+    """One multimodal step of every resident story, sequentially (MLLM half, then the render)."""
+    img_gen_feat = mllm_part(sts, eng, rin, rout, vit, kv_reuse)
+    if adapter is not None:
+        sdxl_part(sts, adapter, img_gen_feat, steps)
     return img_gen_feat
 
 
@@ -241,6 +253,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mllm-only", action="store_true", help="BASELINE configs[1]: no SDXL render, 3-pair stories")
     ap.add_argument("--diffusion-steps", type=int, default=30)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the MLLM half and the render of a round back to back (default: the next round's MLLM half "
+                         "runs on a second HIP stream under the current round's render)")
     ap.add_argument("--stories-per-gpu", type=int, default=4, choices=[1, 2, 3, 4],
                     help="stories resident per GPU, advanced in lock-step (1 = the reference's batch-1 loop)")
     args = ap.parse_args()
@@ -296,13 +311,75 @@ def main():
     eng.select(0).reset()
     one_step()                      # + every other shape of a round (ViT, resamplers, UNet, VAE), whatever --warmup is
     sts[0] = None
-    for _ in range(args.warmup):
-        one_step()
+    # ---- pipelined schedule: the render of round r does not feed round r+1's MLLM half (the context takes the
+    # regressed FEATURE, gen_george.py:224, not the decoded image), so the HBM-bound decode of round r+1 runs on a
+    # second HIP stream, driven by a second host thread, under the MFMA-bound UNet loop of round r.  Work per timed
+    # step is unchanged: K MLLM halves + K renders.
+    import threading
+    overlap = adapter is not None and not args.no_overlap
+    side = torch.cuda.Stream(device=device) if overlap else None
+
+    def next_stories():
+        if sts[0] is None or sts[0][0].step >= STORY_LEN:
+            sts[0] = []
+            for _ in range(SPG):
+                story_no[0] += 1
+                sts[0].append(Story(story_no[0], device))
+        return sts[0]
+
+    def mllm_async(box):
+        def work():
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(side):
+                    box["stories"] = next_stories()
+                    box["feat"] = mllm_part(box["stories"], eng, rin, rout, vit, args.kv_reuse)
+                side.synchronize()
+            except BaseException as ex:   # surfaced by the driver thread (run_rounds)
+                box["err"] = ex
+        th = threading.Thread(target=work)
+        th.start()
+        return th
+
+    def take(box):
+        if "err" in box:
+            raise box["err"]
+        return box["stories"], box["feat"]
+
+    mode = {"overlap": overlap}
+
+    def run_rounds(n):
+        if not mode["overlap"]:
+            for _ in range(n):
+                one_step()
+            return
+        if n <= 0:
+            return
+        torch.cuda.synchronize()
+        box = {}
+        mllm_async(box).join()                         # round 0's MLLM half has nothing to hide under
+        for r in range(n):
+            cur_stories, cur_feat = take(box)
+            box = {}
+            th = mllm_async(box) if r + 1 < n else None
+            sdxl_part(cur_stories, adapter, cur_feat, args.diffusion_steps)
+            if th is not None:
+                th.join()
+        torch.cuda.synchronize()
+
+    try:
+        run_rounds(args.warmup if (args.warmup > 0 or not overlap) else 1)   # >= 1 untimed round checks the schedule
+    except Exception as ex:      # the two-stream schedule is an optimisation: never let it take the measurement down
+        print("bench: overlapped schedule failed (%r); falling back to the sequential one" % (ex,), file=sys.stderr)
+        mode["overlap"] = False
+        torch.cuda.synchronize()
+        sts[0] = None
+        run_rounds(args.warmup)
+    overlap = mode["overlap"]
     sts[0] = None  # timed region starts at a story boundary
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_rounds(args.steps)
     barrier()
     dt_s = time.perf_counter() - t0
     if world > 1:
@@ -416,7 +493,7 @@ def main():
         out = {"metric": metric,
                "value": round(total_steps / dt_s, 4), "unit": "story-steps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True,
-               "story_steps_per_step": SPG,
+               "story_steps_per_step": SPG, "mllm_render_overlap": bool(overlap),
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload, "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
