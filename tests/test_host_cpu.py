@@ -137,3 +137,46 @@ def test_partitioning_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_story_schedule_matches_baseline_shapes():
+    """bench.py's synthetic story (SURVEY §8d schedule): prompt of step i has 115 + 114 i ids, the forced decode
+    schedule is 48 caption ids + <img> + 64 image tokens + </img> + EOS = 115 iterations."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    st = bench.Story(7, "cpu")
+    assert len(st.ids) == 115 and st.ids[0] == bench.BOS and st.ids[-66:] == bench.IMG_IDS
+    f = st.forced()
+    assert len(f) == bench.T_GEN == 115 and f[-1] == bench.EOS and f[48:48 + 66] == bench.IMG_IDS
+    assert all(3 <= t < 32000 for t in f[:48])
+    # context growth of one step (mllm_part's bookkeeping): + caption + the 66 image ids
+    grown = st.ids + f[:bench.CAPTION] + bench.IMG_IDS
+    assert len(grown) == 115 + 114
+    assert tuple(st.image.shape) == (1, 3, 448, 448)
+
+
+def test_xcd_tile_order_is_a_permutation():
+    """Python restatement of ss::xcd_tile (ss_gemm.hip): every (block id) maps to a distinct output tile for any
+    grid, group size and ragged last group — the property the GEMM kernels rely on."""
+    def xcd_tile(idx, MT, NT, GM):
+        total = MT * NT
+        xcd, j = idx & 7, idx >> 3
+        base, rem = total >> 3, total & 7
+        L = xcd * base + min(xcd, rem) + j
+        per_group = GM * NT
+        gidx = L // per_group
+        r = L - gidx * per_group
+        m0 = gidx * GM
+        gm = min(GM, MT - m0)
+        nt = r // gm
+        return m0 + r - nt * gm, nt
+
+    for MT, NT in [(1, 1), (3, 1), (1, 7), (5, 5), (64, 8), (32, 5), (13, 11), (256, 4), (7, 80)]:
+        for GM in (4, 8, 16):
+            seen = {xcd_tile(i, MT, NT, GM) for i in range(MT * NT)}
+            assert len(seen) == MT * NT
+            assert all(0 <= m < MT and 0 <= n < NT for m, n in seen)
