@@ -871,14 +871,15 @@ template <typename T>
 static int autotuned_cfg(GemmArgs& g0, hipStream_t s) {
     const int fallback = pick_cfg(g0.M, g0.N);
     if (Tr<T>::kVec != 8 || g0.M <= 128 || tuning_get("gemm_cfg", 0) || !tuning_get("gemm_autotune", 1)) return fallback;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     const TuneKey key(Tr<T>::kDtype, g0.M, g0.N, g0.K, g0.conv_Cin, g0.conv_stride * 2 + g0.conv_up, g0.conv_H, g0.conv_W);
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = tune_cache().find(key);
         if (it != tune_cache().end()) { g0.swz = it->second / 100; return it->second % 100; }
     }
+    // an untuned shape met under stream capture (the UNet forward graph) cannot be timed: closed-form choice
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     static void* flush = nullptr;
     const size_t flush_bytes = (size_t)320 << 20;
     if (!flush && hipMalloc(&flush, flush_bytes) != hipSuccess) { flush = nullptr; return fallback; }

@@ -139,3 +139,7 @@ def check(rc, what=""):
 
 def set_tuning(key: str, value: int):
     check(lib().ss_set_tuning(key.encode(), int(value)), "ss_set_tuning")
+
+
+def get_tuning(key: str, default: int = 0) -> int:
+    return int(lib().ss_get_tuning(key.encode(), int(default)))

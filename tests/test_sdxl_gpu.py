@@ -241,6 +241,39 @@ def test_pipeline_batched_images_equal_single_calls():
         assert (img[b].float() - one_img.float()).abs().max() <= 1
 
 
+def test_pipeline_graph_replay_equals_eager():
+    """Steps 1..n-1 replay a captured hipGraph of the UNet forward (conditioning and time embedding in stable buffers);
+    the latents must match the eager loop (GroupNorm's fp32 atomics allow last-bit differences only), including a
+    second render with NEW conditioning through the same captured graph."""
+    from seedstory import _lib
+    from seedstory.diffusion import AutoencoderKL, EulerDiscreteScheduler, StableDiffusionXLPipeline
+    m, wd, c = _unet(torch.float32)
+    vae = AutoencoderKL(S.TINY_VAE)
+    vae.load_state_dict(S.synth_weights(S.vae_decoder_shapes(S.TINY_VAE), 2))
+    vae = vae.to(DEV, torch.float32)
+    outs = {}
+    for mode in (1, 0):
+        _lib.set_tuning("unet_graph", mode)
+        try:
+            pipe = StableDiffusionXLPipeline(vae=vae, unet=m, scheduler=EulerDiscreteScheduler())
+            res = []
+            for seed in (230, 240):          # two renders: the second reuses the graph with new conditioning
+                cp, cn = synth.normal_like(seed, (2, 8, 128), 1.0).to(DEV), synth.normal_like(seed + 1, (2, 8, 128), 1.0).to(DEV)
+                pp, pn = synth.normal_like(seed + 2, (2, 80), 1.0).to(DEV), synth.normal_like(seed + 3, (2, 80), 1.0).to(DEV)
+                noise = synth.normal_like(seed + 4, (2, 4, 8, 8), 1.0).to(DEV)
+                res.append(pipe(prompt_embeds=cp, negative_prompt_embeds=cn, pooled_prompt_embeds=pp,
+                                negative_pooled_prompt_embeds=pn, latents=noise, output_type="latent", guidance_scale=7.5,
+                                num_inference_steps=6, height=64, width=64).images.clone())
+            outs[mode] = res
+            if mode == 1:
+                assert any(v is not None for v in pipe._graphs.values()), "graph path was not taken"
+        finally:
+            _lib.set_tuning("unet_graph", 1)
+    for a, b in zip(outs[1], outs[0]):
+        assert rel(a, b) < 1e-5
+    assert rel(outs[1][0], outs[1][1]) > 1e-2      # the two renders really differ
+
+
 def test_resampler_xlv2(golden):
     from src.models_ipa.resampler import ResamplerXLV2
     g, meta = golden
