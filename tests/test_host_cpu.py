@@ -180,3 +180,22 @@ def test_xcd_tile_order_is_a_permutation():
             seen = {xcd_tile(i, MT, NT, GM) for i in range(MT * NT)}
             assert len(seen) == MT * NT
             assert all(0 <= m < MT and 0 <= n < NT for m, n in seen)
+
+
+def test_pipeline_stable_conditioning_buffers():
+    """The captured UNet forward reads its conditioning from buffers whose ADDRESS must survive across renders: same
+    shape -> same storage, refreshed in place (version bump = new-conditioning signal for the K/V cache); new shape ->
+    new storage."""
+    import torch
+    from seedstory.diffusion import StableDiffusionXLPipeline
+    pipe = StableDiffusionXLPipeline(vae=None, unet=None, scheduler=None)
+    a = torch.arange(12, dtype=torch.float32).reshape(2, 6)
+    b1 = pipe._stable("ctx", a)
+    ptr, ver = b1.data_ptr(), b1._version
+    b2 = pipe._stable("ctx", a + 1)
+    assert b2.data_ptr() == ptr and b2._version > ver and torch.equal(b2, a + 1)
+    assert b1 is b2 and b1.data_ptr() != a.data_ptr()
+    b3 = pipe._stable("ctx", torch.zeros(3, 6))
+    assert b3.data_ptr() != ptr and b3.shape == (3, 6)
+    other = pipe._stable("pooled", a)
+    assert other.data_ptr() not in (ptr, b3.data_ptr())
