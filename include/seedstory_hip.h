@@ -8,7 +8,9 @@
  * Rules of the ABI
  *   - plain pointers and sizes only; pointers are DEVICE pointers unless named host_*;
  *   - every call enqueues asynchronously on the caller's `stream` (a hipStream_t passed
- *     as void*; NULL = the legacy default stream) and returns immediately;
+ *     as void*; NULL = the legacy default stream) and returns immediately; the only
+ *     exceptions are named: ss_llama_generate* (return a host count), ss_llama_profile_decode
+ *     and the explicit tuning calls ss_gemm_tune / ss_conv3x3_tune;
  *   - return 0 (SS_OK) or a negative SS_E* code; ss_last_error() gives the message
  *     (thread-local); nothing throws; nothing allocates or frees caller memory —
  *     workspaces are passed in, sized by the *_workspace_bytes() queries; the only
@@ -140,6 +142,31 @@ int ss_attn_decode(const void* q, const void* kcache, const void* vcache, void* 
 int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
             int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, int dtype,
             void* stream);
+
+/* Tile-configuration table of ss_gemm / ss_conv3x3 (16-bit dtypes, M > 128).  The best (tile, XCD group) of a shape
+ * is data: ss_gemm / ss_conv3x3 only LOOK THE SHAPE UP (GEMM keys bucket M up to a multiple of 128) and otherwise use a
+ * closed-form rule — they never time, allocate or synchronise, so they stay asynchronous and hipGraph-capturable.
+ * Entries come from the two explicit tuning calls below or from ss_tune_import.
+ *
+ * ss_gemm_tune / ss_conv3x3_tune: time every candidate tile x tile order for one shape on `stream` with HIP events
+ * (cold caches: a flush fill between runs), operands synthesised (pseudo-random) inside the caller's `workspace`
+ * (>= *_tune_workspace_bytes), SYNCHRONISES, stores the winner in the table; *best_us_host (optional) receives its
+ * time.  `epilogue` may carry SS_EPI_GELU / SS_EPI_GEGLU_PAIR (their arithmetic is timed; bias/residual are not).
+ * ss_tune_lookup: out = {cfg, xcd_group} of the entry (returns 1 and out[0] = -1 when the shape has none).
+ * ss_tune_export / ss_tune_import: the table as int32 records [n][10] = {dtype, M', N, K, conv_Cin,
+ * 2*stride+upsample, conv_H, conv_W, cfg, xcd_group}; export returns the number of entries it holds. */
+size_t ss_gemm_tune_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype);
+int ss_gemm_tune(int64_t M, int64_t N, int64_t K, int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                 void* stream, float* best_us_host);
+size_t ss_conv3x3_tune_workspace_bytes(int64_t batch, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t stride,
+                                       int64_t upsample2x, int dtype);
+int ss_conv3x3_tune(int64_t batch, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t stride, int64_t upsample2x,
+                    int dtype, void* workspace, size_t workspace_bytes, void* stream, float* best_us_host);
+int ss_tune_lookup(int64_t M, int64_t N, int64_t K, int64_t conv_Cin, int64_t conv_H, int64_t conv_W, int64_t stride,
+                   int64_t upsample2x, int dtype, int32_t out[2]);
+int64_t ss_tune_export(int32_t* out, int64_t cap_entries);
+int ss_tune_import(const int32_t* in, int64_t n_entries);
+int ss_tune_clear(void);
 
 /* y[N] = W[N,K] · x[K] — the batch-1 decode projection (weight streaming, HBM-bound).
  * Optional fused prologue: if norm_w != NULL, x is first RMS-normalised (as ss_rmsnorm).
@@ -306,6 +333,12 @@ size_t ss_vit_workspace_bytes(const ss_vit_weights* w, int64_t batch, int dtype)
 /* img [batch,3,image,image] (T) -> tokens [batch, (image/patch)^2, width] */
 int ss_vit_forward(const ss_vit_weights* w, const void* img, void* out, int64_t batch, void* workspace,
                    size_t workspace_bytes, int dtype, void* stream);
+
+/* The transformer trunk alone: VisualAttentionBlock layers [layer0, layer0 + n_layers) of w applied IN PLACE to
+ * tokens x [batch, tokens, width] (qwen_visual.py:275-287: x += attn(ln_1(x)); x += mlp(ln_2(x))); ss_vit_forward is
+ * patch-embed + pos + ln_pre + this call over all layers.  Workspace as ss_vit_workspace_bytes. */
+int ss_vit_blocks(const ss_vit_weights* w, void* x, int64_t batch, int64_t tokens, int64_t layer0, int64_t n_layers,
+                  void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * SDXL de-tokenizer half (the reference reaches these ops through diffusers:

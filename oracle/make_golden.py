@@ -188,26 +188,27 @@ def golden_xlv2(ipa_mod, out):
     out["xlv2.pooled"] = pooled
 
 
-def golden_generate(llama_mod, gen_mod, qwen_mod, out):
+def golden_generate(llama_mod, gen_mod, qwen_mod, out, dtype=torch.float32, tag="gen"):
     """ContinuousLVLM.generate semantics: the reference *model forward*, *logits processor* and
     *Resampler* are the real classes; the HF-4.34 greedy loop around them is restated here
     (transformers 5.x cannot drive this model) — 'parity unpinned' at that boundary."""
     from transformers import LlamaConfig
     d = LLAMA
-    dtype = torch.float32
     cfg = LlamaConfig(hidden_size=d["hidden"], intermediate_size=d["inter"], num_hidden_layers=d["n_layers"],
                       num_attention_heads=d["n_heads"], vocab_size=d["vocab"], max_position_embeddings=4096,
                       rms_norm_eps=1e-5)
     wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
-    wd.update(synth.resampler_weights(21, "input_resampler.", RES_IN["grid"], RES_IN["embed"]))
-    wd.update(synth.resampler_weights(22, "output_resampler.", RES_OUT["grid"], RES_OUT["embed"]))
+    wd.update(synth.resampler_weights(21, "input_resampler.", RES_IN["grid"], RES_IN["embed"], dtype=dtype))
+    wd.update(synth.resampler_weights(22, "output_resampler.", RES_OUT["grid"], RES_OUT["embed"], dtype=dtype))
     m = llama_mod.LlamaForCausalLM(cfg).eval()
     m.load_state_dict({k: v for k, v in wd.items() if "resampler" not in k}, strict=False)
+    m = m.to(dtype)
     m.use_kv_cache_head = False
     rin = qwen_mod.Resampler(grid_size=RES_IN["grid"], embed_dim=256, num_heads=2, kv_dim=256).eval()
     rin.load_state_dict({k[len("input_resampler."):]: v for k, v in wd.items() if k.startswith("input_resampler.")})
     rout = qwen_mod.Resampler(grid_size=RES_OUT["grid"], embed_dim=256, num_heads=2, kv_dim=256).eval()
     rout.load_state_dict({k[len("output_resampler."):]: v for k, v in wd.items() if k.startswith("output_resampler.")})
+    rin, rout = rin.to(dtype), rout.to(dtype)
     proc = gen_mod.AutoImageTokenGenerationProcessor(tokenizer=_FakeTok(), num_img_gen_tokens=64)
     # NOTE tiny config: 16 image-input tokens per image (grid 4), 64 output tokens (as the 7B model).
     n_in = RES_IN["grid"] ** 2
@@ -217,8 +218,12 @@ def golden_generate(llama_mod, gen_mod, qwen_mod, out):
     ids_cmp_mask = torch.zeros_like(input_ids, dtype=torch.bool)
     ids_cmp_mask[0, 14:14 + n_in] = True
     embeds_cmp_mask = torch.tensor([True])
-    image_embeds = synth.normal_like(51, (1, 64, 256), 1.0)
+    image_embeds = synth.normal_like(51, (1, 64, 256), 1.0, dtype=dtype)
+    # fp32: 6 teacher-forced caption tokens then <img>, free-running afterwards.  bf16: the whole tail after </img>
+    # is forced too (EOS), so a one-ulp argmax flip cannot change the sequence the features are compared on
     forced = synth.randint(52, (6,), 3, 250).tolist() + [boi]
+    if dtype != torch.float32:
+        forced = forced + IMG_IDS[1:] + [2]
     with torch.no_grad():
         emb = m.get_input_embeddings()(input_ids)
         emb[ids_cmp_mask] = rin(image_embeds)[embeds_cmp_mask].view(-1, 256)
@@ -250,15 +255,43 @@ def golden_generate(llama_mod, gen_mod, qwen_mod, out):
     mine = O.lvlm_generate(wd, dims, input_ids, image_embeds, embeds_cmp_mask, ids_cmp_mask, IMG_IDS,
                            max_new_tokens=90, forced=forced, n_heads_resampler=2)
     assert mine["generate_ids"] == gen, (mine["generate_ids"], gen)
-    check("generate hidden", mine["hidden"], hidden, 2e-6)
-    check("generate img_gen_feat", mine["img_gen_feat"], feat, 2e-6)
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    check(tag + " hidden", mine["hidden"], hidden, tol)
+    check(tag + " img_gen_feat", mine["img_gen_feat"], feat, tol)
     print("  generate: %d tokens, eoi at %d" % (len(gen), e))
-    out["gen.input_ids"] = input_ids
-    out["gen.image_embeds"] = image_embeds
-    out["gen.forced"] = torch.tensor(forced)
-    out["gen.generate_ids"] = torch.tensor(gen)
-    out["gen.hidden"] = hidden
-    out["gen.img_gen_feat"] = feat
+    out[tag + ".input_ids"] = input_ids
+    out[tag + ".image_embeds"] = image_embeds.float()
+    out[tag + ".forced"] = torch.tensor(forced)
+    out[tag + ".generate_ids"] = torch.tensor(gen)
+    out[tag + ".hidden"] = hidden.float()
+    out[tag + ".img_gen_feat"] = feat.float()
+
+
+VITBLK = dict(width=1664, heads=16, mlp_width=8192, tokens=1024, row_stride=32)   # one ViT-G block, full width
+
+
+def golden_vit_block_full(qwen_mod, out):
+    """One VisualAttentionBlock at ViT-G width (1664, 16 heads x 104, MLP 8192) on 1024 tokens: the REAL reference
+    class (src/models/qwen_visual.py:238-287) in fp32 and in bf16.  Weights and input regenerate from seeds
+    (oracle/synth.py), so the fixture holds only every 32nd output row plus whole-tensor norms."""
+    from functools import partial
+    c = VITBLK
+    for dtype, tag in ((torch.float32, "vitblk_f32"), (torch.bfloat16, "vitblk_bf16")):
+        wd = synth.vit_block_weights(61, c["width"], c["mlp_width"], dtype=dtype)
+        blk = qwen_mod.VisualAttentionBlock(c["width"], c["heads"], c["mlp_width"] / c["width"],
+                                            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)).eval()
+        assert blk.mlp.c_fc.weight.shape[0] == c["mlp_width"]
+        missing, unexpected = blk.load_state_dict(wd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        blk = blk.to(dtype)
+        x = synth.normal_like(161, (c["tokens"], 1, c["width"]), 1.0, dtype=dtype)     # [sq, b, h] (reference layout)
+        with torch.no_grad():
+            ref = blk(x)
+        mine = O.vit_block_forward(wd, "", x.transpose(0, 1), c["heads"]).transpose(0, 1)
+        check(tag, mine, ref, 2e-6 if dtype == torch.float32 else 1e-2)
+        out[tag + ".y_rows"] = ref[::c["row_stride"], 0].float()
+        out[tag + ".y_norm"] = ref.float().norm().reshape(1)
+        out[tag + ".y_absmean"] = ref.float().abs().mean().reshape(1)
 
 
 def main():
@@ -273,9 +306,12 @@ def main():
     print("vit"); golden_vit(qwen_mod, out)
     print("xlv2"); golden_xlv2(ipa_mod, out)
     print("generate"); golden_generate(llama_mod, gen_mod, qwen_mod, out)
+    print("generate bf16"); golden_generate(llama_mod, gen_mod, qwen_mod, out, torch.bfloat16, "gen_bf16")
+    print("vit block, ViT-G width"); golden_vit_block_full(qwen_mod, out)
     out = {k: v.contiguous() for k, v in out.items()}
     save_file(out, os.path.join(GOLD, "hotpath_tiny.safetensors"))
     meta = dict(LLAMA=LLAMA, IMG_IDS=[IMG_IDS[0], IMG_IDS[-1]], RES_IN=RES_IN, RES_OUT=RES_OUT, VIT=VIT, XLV2=XLV2,
+                VITBLK=VITBLK,
                 source="reference modules under /root/reference run on CPU via oracle/ref_shims.py",
                 torch=torch.__version__)
     with open(os.path.join(GOLD, "hotpath_tiny.json"), "w") as f:

@@ -310,6 +310,26 @@ def lvlm_generate(wd: W, dims: LlamaDims, input_ids: Tensor, image_embeds: Optio
 # ---- Qwen ViT-G with attention pool ---------------------------------------------------
 
 
+def vit_block_forward(wd: W, p: str, x: Tensor, heads: int, eps: float = 1e-6) -> Tensor:
+    """VisualAttentionBlock.forward — qwen_visual.py:275-287 with VisualAttention.forward :184-235.
+    x [B, L, width] (batch-first here; the reference is sequence-first, same arithmetic)."""
+    B, L, width = x.shape
+    hd = width // heads
+    y = layernorm(x, wd[p + "ln_1.weight"], wd[p + "ln_1.bias"], eps)
+    qkv = F.linear(y, wd[p + "attn.in_proj.weight"], wd[p + "attn.in_proj.bias"])
+    qkv = qkv.view(B, L, heads, 3 * hd)                      # head-interleaved [q|k|v] (:192-199)
+    q, k, v = qkv.split(hd, dim=-1)
+    q = q.permute(0, 2, 1, 3) / math.sqrt(hd)                # scale on q (:208)
+    k = k.permute(0, 2, 1, 3)
+    v = v.permute(0, 2, 1, 3)
+    pr = torch.matmul(q, k.transpose(-1, -2)).softmax(dim=-1)
+    ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, width)
+    x = x + F.linear(ctx, wd[p + "attn.out_proj.weight"], wd[p + "attn.out_proj.bias"])
+    y = layernorm(x, wd[p + "ln_2.weight"], wd[p + "ln_2.bias"], eps)
+    y = F.gelu(F.linear(y, wd[p + "mlp.c_fc.weight"], wd[p + "mlp.c_fc.bias"]))
+    return x + F.linear(y, wd[p + "mlp.c_proj.weight"], wd[p + "mlp.c_proj.bias"])
+
+
 def vit_forward(wd: W, x: Tensor, *, width: int, layers: int, heads: int, patch: int, out_dim: int,
                 n_queries: int = 256) -> Tensor:
     """VisionTransformerWithAttnPool.forward — qwen_visual.py:376-399 (+VisualAttention
@@ -321,23 +341,8 @@ def vit_forward(wd: W, x: Tensor, *, width: int, layers: int, heads: int, patch:
     x = x.reshape(B, width, -1).permute(0, 2, 1)
     x = x + abs_pos_resize(wd["positional_embedding"], x.shape[1])
     x = layernorm(x, wd["ln_pre.weight"], wd["ln_pre.bias"], eps)
-    L = x.shape[1]
-    hd = width // heads
     for i in range(layers):
-        p = "transformer.resblocks.%d." % i
-        y = layernorm(x, wd[p + "ln_1.weight"], wd[p + "ln_1.bias"], eps)
-        qkv = F.linear(y, wd[p + "attn.in_proj.weight"], wd[p + "attn.in_proj.bias"])
-        qkv = qkv.view(B, L, heads, 3 * hd)                      # head-interleaved [q|k|v] (:192-199)
-        q, k, v = qkv.split(hd, dim=-1)
-        q = q.permute(0, 2, 1, 3) / math.sqrt(hd)                # scale on q (:208)
-        k = k.permute(0, 2, 1, 3)
-        v = v.permute(0, 2, 1, 3)
-        pr = torch.matmul(q, k.transpose(-1, -2)).softmax(dim=-1)
-        ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, width)
-        x = x + F.linear(ctx, wd[p + "attn.out_proj.weight"], wd[p + "attn.out_proj.bias"])
-        y = layernorm(x, wd[p + "ln_2.weight"], wd[p + "ln_2.bias"], eps)
-        y = F.gelu(F.linear(y, wd[p + "mlp.c_fc.weight"], wd[p + "mlp.c_fc.bias"]))
-        x = x + F.linear(y, wd[p + "mlp.c_proj.weight"], wd[p + "mlp.c_proj.bias"])
+        x = vit_block_forward(wd, "transformer.resblocks.%d." % i, x, heads, eps)
     x = resampler_forward(wd, "attn_pool.", x, out_dim // 128, eps)
     x = layernorm(x, wd["ln_post.weight"], wd["ln_post.bias"], eps)
     return x @ wd["proj"]

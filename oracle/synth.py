@@ -141,6 +141,29 @@ def vit_weights(seed: int, width: int, layers: int, heads: int, mlp_width: int, 
     return wd
 
 
+def vit_block_weights(seed: int, width: int, mlp_width: int, dtype=torch.float32):
+    """Keys of ONE ``VisualAttentionBlock`` (qwen_visual.py:238-287), no prefix."""
+    wd = {}
+    s = [seed * 1000]
+
+    def nxt():
+        s[0] += 1
+        return s[0]
+
+    for ln in ("ln_1", "ln_2"):
+        wd[ln + ".weight"] = normal_like(nxt(), (width,), 0.1, 1.0, dtype=dtype)
+        wd[ln + ".bias"] = normal_like(nxt(), (width,), 0.02, dtype=dtype)
+    wd["attn.in_proj.weight"] = normal_like(nxt(), (3 * width, width), 0.02, dtype=dtype)
+    wd["attn.in_proj.bias"] = normal_like(nxt(), (3 * width,), 0.02, dtype=dtype)
+    wd["attn.out_proj.weight"] = normal_like(nxt(), (width, width), 0.02, dtype=dtype)
+    wd["attn.out_proj.bias"] = normal_like(nxt(), (width,), 0.02, dtype=dtype)
+    wd["mlp.c_fc.weight"] = normal_like(nxt(), (mlp_width, width), 0.02, dtype=dtype)
+    wd["mlp.c_fc.bias"] = normal_like(nxt(), (mlp_width,), 0.02, dtype=dtype)
+    wd["mlp.c_proj.weight"] = normal_like(nxt(), (width, mlp_width), 0.02, dtype=dtype)
+    wd["mlp.c_proj.bias"] = normal_like(nxt(), (width,), 0.02, dtype=dtype)
+    return wd
+
+
 def resampler_xlv2_weights(seed: int, dim: int, depth: int, dim_head: int, heads: int, num_queries: int,
                            embedding_dim: int, output1_dim: int, output2_dim: int, ff_mult: int,
                            dtype=torch.float32):

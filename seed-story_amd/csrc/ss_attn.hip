@@ -452,6 +452,258 @@ void flash_attn2_kernel(const AttnArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// (1c) flash attention v3 (bf16 / f16): the v2 data path (32 query rows per wave, K/V tiles by LDS-DMA in a ring,
+//   swizzled K, V^T fragments by ds_read_b64_tr_b16) with the softmax re-cut around what the counters showed limits
+//   v2 at head_dim 64 (rocprofv3: 288 VALU instructions per 32 MFMAs, VALU busy 82 % of the wave's issue time, MFMA
+//   29 %, half of the LDS cycles bank conflicts):
+//   * deferred rescale (guide T13): the running max is only raised — and O rescaled — when some row's tile maximum
+//     exceeds it by more than 2^8; the check is a lane-local max + one wave vote, the cross-lane max reduction and
+//     the 32 accumulator multiplies happen only on that (rare after the first tiles) path.  P <= 2^8 is exact
+//     enough in bf16/f16 (relative precision unchanged) and the final 1/l normalisation removes the common factor;
+//   * the row sum l is accumulated by the matrix cores: one extra MFMA per P fragment against an all-ones operand
+//     (every row of that 16x16 product is sum_k P[q][k]) instead of 32 VALU adds + 4 cross-lane shuffles per tile;
+//     l therefore sums the ROUNDED probabilities, i.e. exactly the weights the PV product uses;
+//   * V image XOR-swizzled in 32-byte units by key row (source-side permutation in the DMA, same XOR on the
+//     transposed read), so the 8 key rows a half-wave touches per ds_read_b64_tr_b16 land on 8 different bank octets.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <typename T> struct OnesFrag;
+template <> struct OnesFrag<bf16_t> { static constexpr uint32_t kPair = 0x3F803F80u; };
+template <> struct OnesFrag<f16_t> { static constexpr uint32_t kPair = 0x3C003C00u; };
+
+template <typename T, int HD, bool VSWZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 3 : 2)))
+void flash_attn3_kernel(const AttnArgs a) {
+    constexpr int V = 8;
+    constexpr int BQ2 = 128;             // query rows per block: 4 waves x 32
+    constexpr int CPR = HD / V;          // 16-byte chunks per key row
+    constexpr int KPI = 64 / CPR;        // keys per DMA instruction
+    constexpr int NI = kBKV / KPI;       // DMA instructions per tile per operand
+    constexpr int IPW = NI / 4;          // ... per wave
+    constexpr int ROWB = HD * 2;         // bytes per key row
+    constexpr int TILE_B = kBKV * ROWB;  // bytes of one K (or V) tile
+    constexpr int NDB = HD / 16, NKB = kBKV / 16, NKS = HD / 32;
+    constexpr float THR_L2 = 8.0f;       // deferred-rescale threshold, log2 units
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.n_heads, h = bh % a.n_heads;
+    const int q0 = blockIdx.x * BQ2;
+    const int hd = a.hd;
+    const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+    const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int shift = a.kv_len - a.q_len;
+    const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void2_t*)smem_raw);
+    const float sl2 = a.scale * 1.4426950408889634f;   // scores kept in the log2 domain
+    const float thr_raw = THR_L2 / fmaxf(sl2, 1e-30f);
+
+    int qi[2];
+    uint4 qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = q0 + wid * 32 + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + grp * 8;
+            qf[qb][ks] = (qi[qb] < a.q_len && d < hd) ? ld16(qp + (int64_t)qi[qb] * a.q_ss + d) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    f32x4_t o[2][NDB], osum[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        osum[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) o[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    float m_run[2] = {-1e30f, -1e30f};
+    const uint4 ones = make_uint4(OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair);
+
+    int kv_end = a.kv_len;
+    if (a.causal_br) {
+        const int lim = q0 + BQ2 - 1 + shift + 1;
+        if (lim < kv_end) kv_end = lim;
+        if (kv_end < 0) kv_end = 0;
+    }
+    const int ntiles = (kv_end + kBKV - 1) / kBKV;
+
+    // V swizzle: 32-byte chunk c of key row r is stored at chunk c ^ vsw(r); rows 128 B apart (head_dim 64) alias
+    // in pairs, rows 256 B apart (head_dim 128) all alias
+    auto vsw = [](int r) { return VSWZ ? (HD <= 64 ? ((r >> 1) & 3) : (r & 7)) : 0; };
+
+    // DMA coordinates of this lane: key row within the instruction and physical chunk
+    const int skey = lane / CPR, spc = lane % CPR;
+    auto issue_tile = [&](int t, int buf) {
+        const uint32_t kbase = lds0 + (uint32_t)(buf * 2 * TILE_B);
+        const uint32_t vbase = kbase + TILE_B;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int key = (wid * IPW + i) * KPI + skey;       // key row inside the tile
+            const int kg = t * kBKV + key;
+            const int lc = spc ^ (key & (CPR - 1));               // K: 16-byte chunks swizzled on the source side
+            const int lv = ((((spc >> 1) ^ vsw(key)) << 1) | (spc & 1));   // V: 32-byte chunks
+            const bool okk = kg < a.kv_len && lc * V < hd;
+            const bool okv = kg < a.kv_len && lv * V < hd;
+            const T* ks = okk ? kp + (int64_t)kg * a.k_ss + lc * V : zero;
+            const T* vs = okv ? vp + (int64_t)kg * a.v_ss + lv * V : zero;
+            const uint32_t roff = (uint32_t)((wid * IPW + i) * KPI * ROWB);
+            attn_dma16(ks, __builtin_amdgcn_readfirstlane(kbase + roff));
+            attn_dma16(vs, __builtin_amdgcn_readfirstlane(vbase + roff));
+        }
+    };
+
+    // per-lane byte offsets of the transposed V reads: key row (grp*4 + l15/4) (+32*kp2, +16), column block db
+    const int vrow = grp * 4 + (l15 >> 2);
+    uint32_t voff[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) voff[db] = (uint32_t)(vrow * ROWB + ((db ^ vsw(vrow)) << 5) + (l15 & 3) * 8);
+
+    constexpr int NSTAGE = HD <= 64 ? 3 : 2;
+    constexpr int DPT = 2 * IPW;               // DMA instructions per tile per wave (K and V)
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+        if (st < ntiles) issue_tile(st, st);
+    int stage = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (NSTAGE == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");   // tile t landed, t+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // ... for every wave; the stage of tile t-1 is drained
+        if (t + NSTAGE - 1 < ntiles) {
+            int ns = stage + NSTAGE - 1;
+            if (ns >= NSTAGE) ns -= NSTAGE;
+            issue_tile(t + NSTAGE - 1, ns);
+        }
+        const char* Kb = smem_raw + stage * 2 * TILE_B;
+        const char* Vb = Kb + TILE_B;
+        if (++stage == NSTAGE) stage = 0;
+        const int t0 = t * kBKV;
+
+        // ---- S^T = K Q^T for both 16-row query blocks ---------------------------------------------
+        f32x4_t s[2][NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            s[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            s[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int r = kb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Kb + r * ROWB + (((ks * 4 + grp) ^ (r & (CPR - 1))) << 4));
+                s[0][kb] = AttnMma<T>::run(kf, qf[0][ks], s[0][kb]);
+                s[1][kb] = AttnMma<T>::run(kf, qf[1][ks], s[1][kb]);
+            }
+        }
+        // ---- softmax numerators (log2 domain, deferred rescale) ----------------------------------------
+        uint4 pfrag[2][NKB / 2];
+        const bool need_mask = a.causal_br || (t0 + kBKV > a.kv_len);   // wave-uniform
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kg = t0 + kb * 16 + grp * 4 + r;
+                        const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
+                        s[qb][kb][r] = ok ? s[qb][kb][r] : -1e30f;
+                    }
+            }
+            // lane-local maximum of the 16 scores: 8 x v_max3_f32.  Written in asm because fmaxf() on MFMA results makes
+            // hipcc emit a canonicalising v_max per operand (12 extra VALU per query block); the first statement carries
+            // the wait states an MFMA result needs before a VALU read (asm is opaque to the hazard recognizer)
+            float tmax;
+            asm volatile("s_nop 7\n\ts_nop 7\n\tv_max3_f32 %0, %1, %2, %3"
+                         : "=v"(tmax) : "v"(s[qb][0][0]), "v"(s[qb][0][1]), "v"(s[qb][0][2]));
+            tmax = max3_asm(tmax, s[qb][0][3], s[qb][1][0]);
+#pragma unroll
+            for (int kb = 1; kb < NKB; ++kb) {
+                tmax = max3_asm(tmax, s[qb][kb][1], s[qb][kb][2]);
+                if (kb + 1 < NKB) tmax = max3_asm(tmax, s[qb][kb][3], s[qb][kb + 1][0]);
+                else tmax = max3_asm(tmax, s[qb][kb][3], s[qb][kb][3]);
+            }
+            if (__any(tmax > m_run[qb] + thr_raw)) {     // some row outgrew its reference maximum: raise it, rescale O and l
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
+                m_run[qb] = m_new;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osum[qb][r] *= alpha;
+            }
+            // masked scores sit at -1e30, so exp2((s - m)*sl2) is exactly 0 for them — unless the whole row is
+            // masked so far (m = -1e30 too); subtracting at least -1e29 keeps that case at exp2(-huge) = 0 as well
+            const float nm = -fmaxf(m_run[qb], -1e29f) * sl2;
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+                float pf[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2][r], sl2, nm));
+                    pf[4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2 + 1][r], sl2, nm));
+                }
+                pfrag[qb][kp2] = pack<T>(pf);
+            }
+        }
+        // ---- O^T += V^T P^T and l += 1^T P^T: V^T fragments by transposed LDS reads, shared by both query blocks --------
+#pragma unroll
+        for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+            osum[0] = AttnMma<T>::run(ones, pfrag[0][kp2], osum[0]);
+            osum[1] = AttnMma<T>::run(ones, pfrag[1][kp2], osum[1]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const char* vb = Vb + voff[db] + kp2 * 32 * ROWB;
+                const v4s_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vb));
+                const v4s_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vb + 16 * ROWB));
+                const uint2 w0 = __builtin_bit_cast(uint2, v0), w1 = __builtin_bit_cast(uint2, v1);
+                const uint4 vfrag = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                o[0][db] = AttnMma<T>::run(vfrag, pfrag[0][kp2], o[0][db]);
+                o[1][db] = AttnMma<T>::run(vfrag, pfrag[1][kp2], o[1][db]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qi[qb] >= a.q_len) continue;
+        const float l = osum[qb][0];         // every row of the ones-product is the row sum
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi[qb] * a.o_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int d = db * 16 + grp * 4;
+            if (d + 3 < hd && ((a.o_ss | a.o_sh | a.o_sb) & 3) == 0) {
+                float pk[8] = {o[qb][db][0] * inv, o[qb][db][1] * inv, o[qb][db][2] * inv, o[qb][db][3] * inv, 0, 0, 0, 0};
+                const uint4 u = pack<T>(pk);
+                *reinterpret_cast<uint2*>(op + d) = make_uint2(u.x, u.y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (d + r < hd) Tr<T>::st(op + d + r, o[qb][db][r] * inv);
+            }
+        }
+    }
+}
+
+template <typename T, int HD, bool VSWZ>
+static int flash3_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    const size_t lds = (size_t)(HD <= 64 ? 3 : 2) * 2 * kBKV * HD * 2;   // ring of (K, V) tiles
+    dim3 grid((unsigned)cdiv(a.q_len, 128), (unsigned)(batch * a.n_heads));
+    hipLaunchKernelGGL((flash_attn3_kernel<T, HD, VSWZ>), grid, dim3(256), lds, s, a);
+    SS_LAUNCH_CHECK("flash_attn3");
+    return SS_OK;
+}
+
 template <typename T, int HD>
 static int flash2_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     const size_t lds = (size_t)(HD <= 64 ? 3 : 2) * 2 * kBKV * HD * 2;   // ring of (K, V) tiles
@@ -483,7 +735,18 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     SS_REQUIRE(a.kv_len > 0, "attention: kv_len == 0");
     if constexpr (V == 8) {
         // v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill its 128-row blocks
-        if (tuning_get("attn_v2", 1) && a.q_len >= 32) {
+        // v3 / v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill their 128-row blocks.
+        // attn_ver: 3 = v3 with the swizzled V image (default), 4 = v3 with the linear V image, 2 = v2
+        const int ver = tuning_get("attn_ver", 3);
+        if (ver >= 3 && a.q_len >= 32) {
+            if (ver == 3) {
+                if (a.hd <= 64) return flash3_launch_hd<T, 64, true>(a, batch, s);
+                return flash3_launch_hd<T, 128, true>(a, batch, s);
+            }
+            if (a.hd <= 64) return flash3_launch_hd<T, 64, false>(a, batch, s);
+            return flash3_launch_hd<T, 128, false>(a, batch, s);
+        }
+        if (ver == 2 && a.q_len >= 32) {
             if (a.hd <= 64) return flash2_launch_hd<T, 64>(a, batch, s);
             return flash2_launch_hd<T, 128>(a, batch, s);
         }

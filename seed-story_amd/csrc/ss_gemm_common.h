@@ -1,0 +1,247 @@
+// Shared pieces of the MFMA GEMM / implicit-GEMM conv kernels (ss_gemm.hip, ss_gemm_sp_*.hip):
+// argument block, MFMA wrappers, the XCD-aware tile order, LDS-DMA helpers and the fused epilogue.
+//
+// C[M,N] = A[M,K] · W[N,K]^T (+bias)(+GELU)(+residual): every nn.Linear on the hot path has this shape with
+// BOTH operands K-contiguous (modeling_llama_xformer.py:228-230,297,191; qwen_visual.py:191,196,259;
+// resampler.py; the diffusers UNet's Linear / Conv2d layers), which is exactly the MFMA fragment shape:
+// lane l of a wave supplies 8 consecutive k of row (l & 15) for k-group (l >> 4).
+// Operand roles are swapped w.r.t. the math so that stores vectorise: the MFMA "A" operand is the WEIGHT
+// tile (rows -> n) and the "B" operand the ACTIVATION tile (cols -> m), so a lane ends up with
+// C[m = l&15][n = 4*(l>>4) .. +3]: four consecutive n per row.
+#pragma once
+#include "ss_common.h"
+
+namespace ss {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int kK = 32;
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    // in-place form with the accumulator pinned to its VGPRs (see gemm_sp_kernel)
+    static __device__ __forceinline__ void run_inplace(const uint4& a, const uint4& b, f32x4_t& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+v"(c)
+                     : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
+    }
+};
+template <> struct Mma<f16_t> {
+    static constexpr int kK = 32;
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void run_inplace(const uint4& a, const uint4& b, f32x4_t& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                     : "+v"(c)
+                     : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf-GELU for 16-bit outputs: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, three orders below a bf16 ulp) on the
+// hardware rcp / exp2 — about a third of the VALU work of libm's branchy erff.  The GEGLU epilogue of the UNet's ff1
+// evaluates 42 M of these per launch, serially after the K loop.
+__device__ __forceinline__ float gelu_erf16(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|v|/sqrt2)
+    return 0.5f * v + 0.5f * fabsf(v) * erf_abs;              // 0.5 v (1 + sign(v) erf(|v|/sqrt2))
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float v) {
+    if constexpr (Tr<T>::kVec == 8) return gelu_erf16(v);
+    else return gelu_erf(v);
+}
+
+struct GemmArgs {
+    const void* A; const void* W; void* C; const void* bias; const void* residual;
+    int M, N, K;
+    int64_t lda, ldw, ldc, ldr;
+    int epi;
+    // per-(batch, n) additive vector (the ResBlock's projected time embedding): rowvec[m / rows_per_batch][n]
+    const void* rowvec; int rows_per_batch; int64_t rowvec_ld;
+    // implicit-GEMM 3x3 convolution over an NHWC tensor (A = [B, H, W, Cin]); K = 9 * Cin
+    int conv_H, conv_W, conv_Cin, conv_stride, conv_up, conv_Ho, conv_Wo;
+    int swz;   // XCD-aware tile order (0 = row-major block ids)
+};
+
+// Linear workgroup id -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and
+// every XCD has a private 4 MB L2, so with row-major tile ids the blocks that share an A row-tile (or a W column-tile)
+// land on eight different L2s and nothing is reused below the Infinity Cache: a K=5120 GEMM then pulls > 5 TB/s through
+// MALL/HBM and is memory-bound, not MFMA-bound.  Remap: (1) XCD k owns a CONTIGUOUS range of logical tile ids,
+// (2) logical ids walk groups of GM m-tiles n-major, so the ~32-64 blocks resident on one XCD form a GM x (32/GM)
+// patch of the output that shares GM A-tiles and a few W-tiles through that XCD's L2.
+__device__ __forceinline__ void xcd_tile_id(int swz, int MT, int NT, int id, int& mt, int& nt) {
+    if (!swz) { mt = id / NT; nt = id - mt * NT; return; }
+    const int total = MT * NT;
+    const int xcd = id & 7, j = id >> 3;
+    const int base = total >> 3, rem = total & 7;
+    const int L = xcd * base + (xcd < rem ? xcd : rem) + j;
+    const int GM = swz;
+    const int per_group = GM * NT;
+    const int gidx = L / per_group, r = L - gidx * per_group;
+    const int m0 = gidx * GM;
+    const int gm = (MT - m0) < GM ? (MT - m0) : GM;
+    nt = r / gm;
+    mt = m0 + r - nt * gm;
+}
+__device__ __forceinline__ void xcd_tile(int swz, int MT, int NT, int& mt, int& nt) {
+    xcd_tile_id(swz, MT, NT, blockIdx.y * gridDim.x + blockIdx.x, mt, nt);
+}
+
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base .. +1 KiB) (lane-linear).
+// Issued from inline asm on purpose: hipcc models the builtin form as an LDS store and drains it
+// (s_waitcnt vmcnt(0)) in front of the next ds_read of the OTHER buffer, serialising the pipeline; the asm
+// form is invisible to that bookkeeping, and the explicit vmcnt+barrier of the caller is the only wait.
+// M0 carries the LDS base and is compiler-reserved: saved/restored inside the same statement.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+__device__ __forceinline__ uint32_t m0_save() {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+    return keep;
+}
+__device__ __forceinline__ void m0_restore(uint32_t keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
+// one 16-byte-per-lane DMA: global (sbase + voff) -> LDS (lds_base + lane*16).  M0 is left modified.
+__device__ __forceinline__ void dma16s(uint32_t voff, const void* sbase, uint32_t lds_base) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Epilogue shared by the LDS-DMA kernels: acc[i][j] is the 16x16 fragment at rows m_base + j*16.., columns
+// n_base + i*16.. (lane l15 -> row, lane group grp -> 4 consecutive columns).
+// A lane owns 4 consecutive columns of one row per fragment, so bias / rowvec / residual / C move as one 8-byte
+// access each when the 4 columns are in range and the operands are 8-byte aligned (every shape on the path).
+// Fragment columns are processed one i at a time (sched_barrier): the FM fragments of a column block have their
+// loads in flight together, but live ranges do not span the whole tile (32 fragments at 256x256).
+template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
+    if constexpr (Tr<T>::kVec == 8) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        float f[8];
+        unpack<T>(make_uint4(u.x, u.y, 0, 0), f);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+    } else {
+        const float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+}
+
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
+                                              int l15, int grp) {
+    const int M = g.M, N = g.N;
+    T* __restrict__ C = (T*)g.C;
+    const T* bias = (const T*)g.bias;
+    const T* res = (const T*)g.residual;
+    constexpr size_t AL = 4 * sizeof(T) - 1;   // alignment mask of a 4-element access
+    const bool vec_ok = (((size_t)g.bias | (size_t)g.residual | (size_t)g.rowvec) & AL) == 0 &&
+                        ((g.ldr | g.rowvec_ld) & 3) == 0;
+    const bool vec_c = ((size_t)g.C & AL) == 0 && (g.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n0 = n_base + i * 16 + grp * 4;
+        const bool full = n0 + 3 < N;
+        const bool fast = full && vec_ok;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.epi & SS_EPI_BIAS) {
+            if (fast) ld4<T>(bias + n0, bv);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n0 + r < N) bv[r] = Tr<T>::ld(bias + n0 + r);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m_base + j * 16 + l15;
+            if (m >= M) continue;
+            float v[4];
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g.rowvec) {
+                const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
+                if (fast) ld4<T>(rp + n0, rv);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n0 + r < N) rv[r] = Tr<T>::ld(rp + n0 + r);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[i][j][r] + bv[r];
+                if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
+                v[r] = Tr<T>::rnd(t);
+                if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);   // h = conv(x) + temb[:, :, None, None]
+            }
+            if (g.epi & SS_EPI_RESIDUAL) {
+                if (fast) {
+                    float rr[4];
+                    ld4<T>(res + (int64_t)m * g.ldr + n0, rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
+                }
+            }
+            if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
+                const float o0 = v[0] * Tr<T>::rnd(gelu_for<T>(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_for<T>(v[3]));
+                if (full && ((g.ldc & 1) == 0) && (((size_t)g.C & 3) == 0) && Tr<T>::kVec == 8) {
+                    float pk[8] = {o0, o1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<uint32_t*>(C + (int64_t)m * g.ldc + (n0 >> 1)) = pack<T>(pk).x;
+                } else {
+                    if (n0 + 1 < N) Tr<T>::st(C + (int64_t)m * g.ldc + (n0 >> 1), o0);
+                    if (n0 + 3 < N) Tr<T>::st(C + (int64_t)m * g.ldc + (n0 >> 1) + 1, o1);
+                }
+                continue;
+            }
+            if (full && vec_c && Tr<T>::kVec == 8) {
+                float pk[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
+                const uint4 u = pack<T>(pk);
+                *reinterpret_cast<uint2*>(C + (int64_t)m * g.ldc + n0) = make_uint2(u.x, u.y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < N) Tr<T>::st(C + (int64_t)m * g.ldc + n0 + r, v[r]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Software-pipelined LDS-DMA kernels (ss_gemm_sp.inc, instantiated per dtype in ss_gemm_sp_{bf16,f16}.hip).
+// Returns SS_OK, or 1 when `cfg` is not a pipelined configuration / the shape is not eligible (the caller
+// then falls back to the double-buffered kernel).
+template <typename T> int gemm_sp_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
+
+}  // namespace ss

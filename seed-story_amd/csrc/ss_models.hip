@@ -115,6 +115,38 @@ int ss_resampler_forward(const ss_resampler_weights* w, const void* x, void* y, 
 // ---------------------------------------------------------------------------------------------
 // ViT trunk
 // ---------------------------------------------------------------------------------------------
+// VisualAttentionBlock layers [l0, l0 + nl) in place on x [batch, L, width]; y/qkv/ctx/hm are scratch
+static int vit_blocks(const ss_vit_weights* w, void* x, void* y, void* qkv, void* ctx, void* hm, int64_t batch, int64_t L,
+                      int64_t l0, int64_t nl, int dtype, void* stream) {
+    const size_t e = dtype_size(dtype);
+    const int64_t rows = batch * L, Wd = w->width, hd = Wd / w->n_heads;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    for (int64_t l = l0; l < l0 + nl; ++l) {
+        const ss_vit_layer_weights& Lw = w->layers[l];
+        if ((rc = ss_layernorm(x, Lw.ln1_w, Lw.ln1_b, y, rows, Wd, w->ln_eps, dtype, stream))) return rc;
+        if ((rc = gemm_dev(y, Lw.in_w, qkv, rows, 3 * Wd, Wd, Wd, Wd, 3 * Wd, Lw.in_b, nullptr, 0, SS_EPI_BIAS, dtype, s)))
+            return rc;
+        // per token the in_proj output is [head][q(hd) | k(hd) | v(hd)]  (:192-199)
+        const char* q = (const char*)qkv;
+        if ((rc = ss_attention(q, q + (size_t)hd * e, q + (size_t)2 * hd * e, ctx, batch, w->n_heads, L, L, hd,
+                               L * 3 * Wd, 3 * hd, 3 * Wd, L * 3 * Wd, 3 * hd, 3 * Wd, L * 3 * Wd, 3 * hd, 3 * Wd, L * Wd,
+                               hd, Wd, 1.0f / sqrtf((float)hd), 0, dtype, stream)))
+            return rc;
+        if ((rc = gemm_dev(ctx, Lw.out_w, x, rows, Wd, Wd, Wd, Wd, Wd, Lw.out_b, x, Wd, SS_EPI_BIAS | SS_EPI_RESIDUAL,
+                           dtype, s)))
+            return rc;
+        if ((rc = ss_layernorm(x, Lw.ln2_w, Lw.ln2_b, y, rows, Wd, w->ln_eps, dtype, stream))) return rc;
+        if ((rc = gemm_dev(y, Lw.fc_w, hm, rows, w->mlp_width, Wd, Wd, Wd, w->mlp_width, Lw.fc_b, nullptr, 0,
+                           SS_EPI_BIAS | SS_EPI_GELU, dtype, s)))
+            return rc;
+        if ((rc = gemm_dev(hm, Lw.proj_w, x, rows, Wd, w->mlp_width, w->mlp_width, w->mlp_width, Wd, Lw.proj_b, x, Wd,
+                           SS_EPI_BIAS | SS_EPI_RESIDUAL, dtype, s)))
+            return rc;
+    }
+    return SS_OK;
+}
+
 size_t ss_vit_workspace_bytes(const ss_vit_weights* w, int64_t batch, int dtype) {
     if (!w) return 0;
     const size_t e = dtype_size(dtype);
@@ -153,30 +185,27 @@ int ss_vit_forward(const ss_vit_weights* w, const void* img, void* out, int64_t 
         return rc;
     if ((rc = ss_add_bcast(y, w->pos, y, batch, L, Wd, L * Wd, dtype, stream))) return rc;
     if ((rc = ss_layernorm(y, w->ln_pre_w, w->ln_pre_b, x, rows, Wd, w->ln_eps, dtype, stream))) return rc;
-    for (int l = 0; l < w->n_layers; ++l) {
-        const ss_vit_layer_weights& Lw = w->layers[l];
-        if ((rc = ss_layernorm(x, Lw.ln1_w, Lw.ln1_b, y, rows, Wd, w->ln_eps, dtype, stream))) return rc;
-        if ((rc = gemm_dev(y, Lw.in_w, qkv, rows, 3 * Wd, Wd, Wd, Wd, 3 * Wd, Lw.in_b, nullptr, 0, SS_EPI_BIAS, dtype, s)))
-            return rc;
-        // per token the in_proj output is [head][q(hd) | k(hd) | v(hd)]  (:192-199)
-        const char* q = (const char*)qkv;
-        if ((rc = ss_attention(q, q + (size_t)hd * e, q + (size_t)2 * hd * e, ctx, batch, w->n_heads, L, L, hd,
-                               L * 3 * Wd, 3 * hd, 3 * Wd, L * 3 * Wd, 3 * hd, 3 * Wd, L * 3 * Wd, 3 * hd, 3 * Wd, L * Wd,
-                               hd, Wd, 1.0f / sqrtf((float)hd), 0, dtype, stream)))
-            return rc;
-        if ((rc = gemm_dev(ctx, Lw.out_w, x, rows, Wd, Wd, Wd, Wd, Wd, Lw.out_b, x, Wd, SS_EPI_BIAS | SS_EPI_RESIDUAL,
-                           dtype, s)))
-            return rc;
-        if ((rc = ss_layernorm(x, Lw.ln2_w, Lw.ln2_b, y, rows, Wd, w->ln_eps, dtype, stream))) return rc;
-        if ((rc = gemm_dev(y, Lw.fc_w, hm, rows, w->mlp_width, Wd, Wd, Wd, w->mlp_width, Lw.fc_b, nullptr, 0,
-                           SS_EPI_BIAS | SS_EPI_GELU, dtype, s)))
-            return rc;
-        if ((rc = gemm_dev(hm, Lw.proj_w, x, rows, Wd, w->mlp_width, w->mlp_width, w->mlp_width, Wd, Lw.proj_b, x, Wd,
-                           SS_EPI_BIAS | SS_EPI_RESIDUAL, dtype, s)))
-            return rc;
-    }
+    if ((rc = vit_blocks(w, x, y, qkv, ctx, hm, batch, L, 0, w->n_layers, dtype, stream))) return rc;
     SS_HIP(hipMemcpyAsync(out, x, rows * Wd * e, hipMemcpyDeviceToDevice, s));
     return SS_OK;
+}
+
+int ss_vit_blocks(const ss_vit_weights* w, void* x, int64_t batch, int64_t tokens, int64_t layer0, int64_t n_layers,
+                  void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    SS_REQUIRE(w && x && workspace && batch > 0 && tokens > 0, "vit_blocks: bad arguments");
+    SS_REQUIRE(layer0 >= 0 && n_layers >= 0 && layer0 + n_layers <= w->n_layers, "vit_blocks: layer range");
+    SS_REQUIRE(w->width % w->n_heads == 0, "vit_blocks: bad geometry");
+    const size_t e = dtype_size(dtype);
+    const size_t rows = (size_t)batch * tokens, Wd = w->width;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t need = up(rows * Wd * e) + up(rows * 3 * Wd * e) + up(rows * Wd * e) + up(rows * w->mlp_width * e);
+    SS_REQUIRE(workspace_bytes >= need, "vit_blocks: workspace too small");
+    Bump b{(char*)workspace, 0, workspace_bytes};
+    void* y = b.take(rows * Wd * e);
+    void* qkv = b.take(rows * 3 * Wd * e);
+    void* ctx = b.take(rows * Wd * e);
+    void* hm = b.take(rows * w->mlp_width * e);
+    return vit_blocks(w, x, y, qkv, ctx, hm, batch, tokens, layer0, n_layers, dtype, stream);
 }
 
 }  // extern "C"

@@ -72,6 +72,14 @@ PROTOTYPES = {
     "ss_attn_decode_workspace_bytes": (sz, [i64, i64]),
     "ss_attn_decode": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "ss_gemm": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, C.c_int, vp]),
+    "ss_gemm_tune_workspace_bytes": (sz, [i64, i64, i64, C.c_int]),
+    "ss_gemm_tune": (C.c_int, [i64, i64, i64, C.c_int, C.c_int, vp, sz, vp, C.POINTER(f32)]),
+    "ss_conv3x3_tune_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, C.c_int]),
+    "ss_conv3x3_tune": (C.c_int, [i64, i64, i64, i64, i64, i64, i64, C.c_int, vp, sz, vp, C.POINTER(f32)]),
+    "ss_tune_lookup": (C.c_int, [i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, i32p]),
+    "ss_tune_export": (i64, [i32p, i64]),
+    "ss_tune_import": (C.c_int, [i32p, i64]),
+    "ss_tune_clear": (C.c_int, []),
     "ss_gemv": (C.c_int, [vp, vp, vp, i64, i64, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
     "ss_gemv_batched": (C.c_int, [vp, vp, vp, i64, i64, i64, vp, f32, vp, vp, C.c_int, C.c_int, vp]),
     "ss_imgproc_argmax": (C.c_int, [vp, i64, vp, vp, i64, vp, C.c_int, vp]),
@@ -92,6 +100,7 @@ PROTOTYPES = {
     "ss_resampler_forward": (C.c_int, [C.POINTER(ResamplerWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
     "ss_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i64, C.c_int]),
     "ss_vit_forward": (C.c_int, [C.POINTER(VitWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
+    "ss_vit_blocks": (C.c_int, [C.POINTER(VitWeights), vp, i64, i64, i64, i64, vp, sz, C.c_int, vp]),
     "ss_conv3x3": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, C.c_int, vp]),
     "ss_groupnorm": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, C.c_int, C.c_int, vp]),
     "ss_geglu": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),
@@ -128,6 +137,8 @@ def lib():
         if l.ss_abi_version() != 1:
             raise SSError("ABI version mismatch")
         _lib = l
+        from . import tune
+        tune.load_default_table()
     return _lib
 
 

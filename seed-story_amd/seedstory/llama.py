@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, tune
 from ._lib import check, lib
 
 ATTN_PROJ = ("q_proj", "k_proj", "v_proj", "o_proj")
@@ -215,6 +215,10 @@ class LlamaEngine:
         M = embeds.shape[0]
         hid = torch.empty(M, self.hidden, dtype=self.dtype, device=self.device) if want_hidden else None
         pid = None if pos_ids is None else pos_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        if M > 128:      # the four prefill projections of this row-count bucket (tile table: seedstory/tune.py)
+            code, Hd, I = ops.dt(self.dtype), self.hidden, self.inter
+            for n, k in ((3 * Hd, Hd), (Hd, Hd), (2 * I, Hd), (Hd, I)):
+                tune.ensure_gemm(M, n, k, code, 0, self.device)
         check(lib().ss_llama_prefill(self._h, embeds.data_ptr(), M, ops.p(pid), ops.p(hid), ops.stream()),
               "ss_llama_prefill")
         return hid

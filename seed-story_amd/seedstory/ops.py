@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, tune
 from ._lib import EPI_BIAS, EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SILU_MUL, check, lib
 
 _DT = {torch.float32: _lib.SS_F32, torch.bfloat16: _lib.SS_BF16, torch.float16: _lib.SS_F16}
@@ -159,6 +159,7 @@ def gemm(a, w, bias=None, residual=None, gelu=False, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    tune.ensure_gemm(M, N, K, dt(a), epi, a.device)
     check(lib().ss_gemm(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, dt(a), stream()),
           "ss_gemm")
     return out
@@ -170,6 +171,7 @@ def gemm_geglu(a, w_pairs, bias_pairs):
     M, K = a.shape
     N = w_pairs.shape[0]
     out = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
+    tune.ensure_gemm(M, N, K, dt(a), _lib.EPI_GEGLU_PAIR, a.device)
     check(lib().ss_gemm(p(a), p(w_pairs), p(out), M, N, K, K, K, N // 2, p(bias_pairs), None, 0,
                         _lib.EPI_BIAS | _lib.EPI_GEGLU_PAIR, dt(a), stream()), "ss_gemm(geglu)")
     return out
@@ -223,6 +225,7 @@ def conv3x3(x, w, B, H, W, stride=1, upsample=False, bias=None, rowvec=None, res
     Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
     Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
     y = torch.empty(B * Ho * Wo, Cout, dtype=x.dtype, device=x.device)
+    tune.ensure_conv(B, H, W, Cin, Cout, stride, upsample, dt(x), x.device)
     check(lib().ss_conv3x3(p(x), p(w), p(y), B, H, W, Cin, Cout, stride, int(upsample), p(bias), p(rowvec),
                            rowvec_stride, p(residual), dt(x), stream()), "ss_conv3x3")
     return y, Ho, Wo

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from seedstory import _lib, ops
+from seedstory import _lib, ops, tune
 from seedstory._lib import check, lib
 
 
@@ -153,6 +153,9 @@ class Resampler(nn.Module):
         w, _keep = self._weights(L)
         y = torch.empty(B, self.num_queries, self.embed_dim, dtype=x.dtype, device=x.device)
         code = ops.dt(x)
+        E = self.embed_dim
+        for m, n, k in ((B * L, E, self.kv_dim), (self.num_queries, E, E), (B * L, E, E), (B * self.num_queries, E, E)):
+            tune.ensure_gemm(m, n, k, code, 0, x.device)           # tile table entries of this module's projections
         nbytes = lib().ss_resampler_workspace_bytes(C.byref(w), B, code)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         check(lib().ss_resampler_forward(C.byref(w), x.data_ptr(), y.data_ptr(), B, ws.data_ptr(), nbytes, code,
@@ -253,6 +256,9 @@ class VisionTransformerWithAttnPool(nn.Module):
         tokens = self.grid_size[0] * self.grid_size[1]
         feat = torch.empty(B, tokens, self.width, dtype=x.dtype, device=x.device)
         code = ops.dt(x)
+        rows, Wd = B * tokens, self.width
+        for n, k, epi in ((Wd, w.kpad, 0), (3 * Wd, Wd, 0), (Wd, Wd, 0), (self.mlp_width, Wd, _lib.EPI_GELU), (Wd, self.mlp_width, 0)):
+            tune.ensure_gemm(rows, n, k, code, epi, x.device)
         nbytes = lib().ss_vit_workspace_bytes(C.byref(w), B, code)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         check(lib().ss_vit_forward(C.byref(w), x.data_ptr(), feat.data_ptr(), B, ws.data_ptr(), nbytes, code,

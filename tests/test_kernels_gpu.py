@@ -205,7 +205,7 @@ def test_gemm_every_tile_config(ops, cfg):
     assert rel(y, a.float() @ w.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 25, 26, 28, 29])
+@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39])
 @pytest.mark.parametrize("M,N,K", [(200, 300, 512), (1024, 640, 1280), (333, 1000, 64), (4096, 256, 2560), (130, 72, 192)])
 def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
     """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-23 software-pipelined) on ragged and
@@ -231,6 +231,54 @@ def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
     if y3 is not None:
         full = (ref + bias.float()).to(dtype).float()
         assert rel(y3, full[:, 0::2] * torch.nn.functional.gelu(full[:, 1::2].to(dtype)).float()) < 8e-3
+
+
+@pytest.mark.parametrize("cfg", [30, 31, 32, 33, 35, 36, 38, 39])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320])
+def test_gemm_ring_depth_k_tile_edge_cases(ops, cfg, K):
+    """1 .. 5 K tiles through the 2- and 3-slot LDS rings (prologue / drain paths of the counted vmcnt waits) and the
+    uneven DMA deal of the 256x160 tile."""
+    from seedstory import _lib
+    dtype = torch.bfloat16
+    M, N = 520, 330
+    a = dev(synth.normal_like(190, (M, K), 1.0, dtype=dtype))
+    w = dev(synth.normal_like(191, (N, K), 0.05, dtype=dtype))
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        ys = [ops.gemm(a, w) for _ in range(4)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(ys[0], a.float() @ w.float().t()) < 4e-3
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+
+
+@pytest.mark.parametrize("cfg", [33, 35, 36, 38, 39])
+@pytest.mark.parametrize("M,N,K", [(8200, 3840, 192), (8192, 10240, 128), (8192, 5120, 64), (16384, 2560, 640)])
+def test_gemm_persistent_multi_tile(ops, cfg, M, N, K):
+    """Persistent configurations with several output tiles per workgroup (grid capped at the CU count): the next tile's
+    first K tiles are DMA'd under the epilogue of the current one.  Repeated launches must be bit-identical (a
+    staging race shows up as run-to-run drift), results equal fp32 math on the bf16 inputs."""
+    from seedstory import _lib
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + cfg)
+    a = torch.randn(M, K, device="cuda", dtype=dtype, generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, device="cuda", dtype=dtype, generator=g)
+    res = torch.randn(M, N, device="cuda", dtype=dtype, generator=g)
+    ref = ((a.float() @ w.float().t() + bias.float()).to(dtype) + res).float()
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        ys = [ops.gemm(a, w, bias=bias, residual=res) for _ in range(4)]
+        yg = ops.gemm_geglu(a, w, bias)
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(ys[0], ref) < 4e-3
+    assert float((ys[0].float() - ref).abs().max()) < 0.08 * float(ref.abs().max())
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+    full = (a.float() @ w.float().t() + bias.float()).to(dtype).float()
+    assert rel(yg, full[:, 0::2] * torch.nn.functional.gelu(full[:, 1::2].to(dtype)).float()) < 8e-3
 
 
 def attn_ref(q, k, v, n_heads, scale, causal_br):

@@ -126,3 +126,34 @@ def test_lora_linear_equals_merged():
     y = O.lora_linear(x, w, a, b, 2.0)
     ym = torch.nn.functional.linear(x, O.lora_merge(w, a, b, 2.0))
     assert rel(ym, y) < 1e-6
+
+
+def test_lvlm_generate_bf16(golden):
+    """The bf16 reference run of ContinuousLVLM.generate (real forward / processor / Resampler classes in bf16 on
+    CPU): the oracle rounds where the reference rounds."""
+    g, meta = golden
+    wd, dims = _llama(meta, torch.bfloat16)
+    wd.update(synth.resampler_weights(21, "input_resampler.", meta["RES_IN"]["grid"], 256, dtype=torch.bfloat16))
+    wd.update(synth.resampler_weights(22, "output_resampler.", meta["RES_OUT"]["grid"], 256, dtype=torch.bfloat16))
+    input_ids = g["gen_bf16.input_ids"]
+    n_in = meta["RES_IN"]["grid"] ** 2
+    mask = torch.zeros_like(input_ids, dtype=torch.bool)
+    mask[0, 14:14 + n_in] = True
+    out = O.lvlm_generate(wd, dims, input_ids, g["gen_bf16.image_embeds"].bfloat16(), torch.tensor([True]), mask,
+                          _img_ids(meta), max_new_tokens=90, forced=g["gen_bf16.forced"].tolist(), n_heads_resampler=2)
+    assert out["generate_ids"] == g["gen_bf16.generate_ids"].tolist()
+    assert rel(out["img_gen_feat"], g["gen_bf16.img_gen_feat"]) < 1e-2
+    # the reference's own bf16-vs-fp32 distance on the regressed feature (what "bf16 parity" can mean at best)
+    assert rel(g["gen_bf16.img_gen_feat"], g["gen.img_gen_feat"]) < 5e-2
+
+
+def test_vit_block_full_width(golden):
+    """One VisualAttentionBlock at ViT-G width (1664 / 16 heads of 104 / MLP 8192, 1024 tokens) against the rows
+    the REAL reference class produced (oracle/make_golden.py::golden_vit_block_full)."""
+    g, meta = golden
+    c = meta["VITBLK"]
+    wd = synth.vit_block_weights(61, c["width"], c["mlp_width"])
+    x = synth.normal_like(161, (c["tokens"], 1, c["width"]), 1.0).transpose(0, 1)
+    y = O.vit_block_forward(wd, "", x, c["heads"])[0]
+    assert rel(y[::c["row_stride"]], g["vitblk_f32.y_rows"]) < 2e-6
+    assert abs(float(y.norm()) / float(g["vitblk_f32.y_norm"]) - 1) < 1e-6

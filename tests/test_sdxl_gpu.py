@@ -55,7 +55,7 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
-@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 25, 26, 28, 29])
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
 def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
@@ -84,6 +84,28 @@ def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
     assert rel(nchw(y.cpu(), B, Ho, Wo), ref + tv.float()[:, :, None, None] + res.float()) < 1e-2
     for other, _, _ in ys[1:]:
         assert torch.equal(other, y)
+
+
+@pytest.mark.parametrize("cfg", [33, 36, 38, 39])
+def test_conv3x3_persistent_multi_tile(cfg):
+    """Implicit-GEMM conv through the persistent configurations with > 1 output tile per workgroup."""
+    from seedstory import _lib, ops
+    from seedstory.diffusion import _conv_w
+    dtype = torch.bfloat16
+    B, Ci, Co, H, W = 8, 64, 640, 64, 64
+    g = torch.Generator(device=DEV).manual_seed(cfg)
+    x = torch.randn(B, Ci, H, W, device=DEV, dtype=dtype, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, device=DEV, generator=g) / math.sqrt(9 * Ci)).to(dtype)
+    b = torch.randn(Co, device=DEV, dtype=dtype, generator=g) * 0.5
+    ref = F.conv2d(x.float().cpu(), w.float().cpu(), b.float().cpu(), padding=1)     # CPU reference (no MIOpen)
+    _lib.set_tuning("gemm_cfg", cfg)
+    try:
+        ys = [ops.conv3x3(nhwc(x), _conv_w(w), B, H, W, bias=b)[0] for _ in range(3)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(nchw(ys[0], B, H, W), ref) < 4e-3
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
 
 
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 5, 7, 32), (1, 320, 16, 16, 32), (2, 128, 33, 9, 32), (1, 1920, 4, 4, 32)])
