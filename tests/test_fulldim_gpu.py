@@ -325,6 +325,111 @@ def test_sdxl_attention_shapes_bf16(B, heads, L, Lk, ver):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# (c2) whole SDXL-base blocks at full size vs the independent oracle (oracle/sdxl_oracle.py), fp32 weights -> bf16 run
+# ---------------------------------------------------------------------------------------------------------------------
+def _nhwc(x):
+    B, C, Hh, Ww = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * Hh * Ww, C).contiguous()
+
+
+def _nchw(y, B, Hh, Ww):
+    return y.reshape(B, Hh, Ww, -1).permute(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def sdxl_unet_bf16():
+    from seedstory.diffusion import UNet2DConditionModel
+    m = UNet2DConditionModel().to(DEV, torch.bfloat16).init_synthetic(11)
+    # non-trivial norm affine parameters and biases (init_synthetic leaves them at 1 / 0)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for n, p in m.named_parameters():
+        if p.dim() == 1:
+            p.data.copy_(((1.0 if n.endswith("weight") else 0.0) + 0.1 * torch.randn(p.shape, device=DEV, generator=g)).to(p.dtype))
+    m._prep = None
+    return m
+
+
+def _block_weights(m, prefix):
+    return {k: v.detach().float().cpu() for k, v in m.state_dict().items() if k.startswith(prefix + ".")}
+
+
+@pytest.mark.parametrize("name,cin,skip,cout,res", [("down_blocks.0.resnets.0", 320, 0, 320, 128),
+                                                      ("up_blocks.1.resnets.0", 640, 1280, 640, 64),
+                                                      ("down_blocks.2.resnets.0", 640, 0, 1280, 32)])
+def test_sdxl_resblock_full_size(sdxl_unet_bf16, name, cin, skip, cout, res):
+    """ResnetBlock2D at SDXL-base size (incl. the channel-concat + 1x1-shortcut form of the up path) in bf16, against
+    the oracle run in fp32 and in bf16 (same rounding points)."""
+    import sdxl_oracle as S
+    from seedstory import ops
+    m = sdxl_unet_bf16
+    P = m._prepare()
+    B, G, dt = 2, 32, torch.bfloat16
+    wd = _block_weights(m, name)
+    x = synth.normal_like(31, (B, cin + skip, res, res), 1.0)
+    emb = synth.normal_like(32, (B, 1280), 1.0)
+    ref32 = S.resnet_block(wd, name, x, emb, G)
+    bf = {k: v.to(dt) for k, v in wd.items()}
+    refbf = S.resnet_block(bf, name, x.to(dt), emb.to(dt), G)
+    xd = _nhwc(x).to(DEV, dt)
+    temb_act = ops.gemm(ops.silu(emb.to(DEV, dt)), P["temb_all.weight"], bias=P["temb_all.bias"])
+    y = m._resnet(P, name, xd, B, res, res, temb_act, G)
+    y = _nchw(y, B, res, res)
+    e_bf, e_32, theirs = rel(y, refbf), rel(y, ref32), rel(refbf, ref32)
+    print("resblock %s: HIP vs oracle-bf16 %.3e | vs oracle-fp32 %.3e | oracle bf16 vs fp32 %.3e" % (name, e_bf, e_32, theirs))
+    assert e_bf < 1e-2 and e_32 <= 1.5 * theirs + 1e-3
+
+
+@pytest.mark.parametrize("name,ch,heads,res", [("mid_block.attentions.0", 1280, 20, 32), ("down_blocks.1.attentions.0", 640, 10, 64)])
+def test_sdxl_transformer_block_full_size(sdxl_unet_bf16, name, ch, heads, res):
+    """Transformer2DModel with ONE BasicTransformerBlock at SDXL-base size (self-attention over 1024 / 4096 tokens,
+    cross-attention to 64 x 2048 context, GEGLU feed-forward) in bf16 vs the oracle."""
+    import sdxl_oracle as S
+    m = sdxl_unet_bf16
+    P = m._prepare()
+    B, G, dt = 2, 32, torch.bfloat16
+    wd = {k: v for k, v in _block_weights(m, name).items() if ".transformer_blocks." not in k or ".transformer_blocks.0." in k}
+    x = synth.normal_like(41, (B, ch, res, res), 1.0)
+    ctx = synth.normal_like(42, (B, 64, 2048), 1.0)
+    ref32 = S.transformer_2d(wd, name, x, ctx, heads, 1, G)
+    bf = {k: v.to(dt) for k, v in wd.items()}
+    refbf = S.transformer_2d(bf, name, x.to(dt), ctx.to(dt), heads, 1, G)
+    m._ctx_kv = {}
+    ctxd = ctx.to(DEV, dt).contiguous()
+    y = m._transformer(P, name, _nhwc(x).to(DEV, dt), B, res * res, ctxd.view(B * 64, -1), 64, heads, 1, G)
+    m._ctx_kv = {}
+    y = _nchw(y, B, res, res)
+    e_bf, e_32, theirs = rel(y, refbf), rel(y, ref32), rel(refbf, ref32)
+    print("transformer %s: HIP vs oracle-bf16 %.3e | vs oracle-fp32 %.3e | oracle bf16 vs fp32 %.3e" % (name, e_bf, e_32, theirs))
+    assert e_bf < 1e-2 and e_32 <= 1.5 * theirs + 1e-3
+
+
+def test_sdxl_vae_up_block_full_size():
+    """VAE decoder ResBlock 512 -> 256 at 512^2 followed by the nearest-2x up-conv 256 -> 256 to 1024^2 (the shapes that
+    dominate the decode), bf16 vs the oracle in fp32 / bf16."""
+    import sdxl_oracle as S
+    from seedstory import ops
+    from seedstory.diffusion import AutoencoderKL
+    dt = torch.bfloat16
+    vae = AutoencoderKL().to(DEV, dt).init_synthetic(12)
+    P = vae._prepare()
+    rn, un = "decoder.up_blocks.2.resnets.0", "decoder.up_blocks.2.upsamplers.0.conv"
+    wd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items() if k.startswith(rn + ".") or k.startswith(un + ".")}
+    x = synth.normal_like(51, (1, 512, 256, 256), 1.0)          # 256^2 keeps the CPU oracle at ~0.2 TFLOP
+    h32 = S.resnet_block(wd, rn, x, None, 32, 1e-6)
+    ref32 = F.conv2d(F.interpolate(h32, scale_factor=2.0, mode="nearest"), wd[un + ".weight"], wd[un + ".bias"], padding=1)
+    bf = {k: v.to(dt) for k, v in wd.items()}
+    hbf = S.resnet_block(bf, rn, x.to(dt), None, 32, 1e-6)
+    refbf = F.conv2d(F.interpolate(hbf, scale_factor=2.0, mode="nearest"), bf[un + ".weight"], bf[un + ".bias"], padding=1)
+    h = vae._resnet(P, rn, _nhwc(x).to(DEV, dt), 1, 256, 256, 32)
+    y, Ho, Wo = ops.conv3x3(h, P[un + ".weight"], 1, 256, 256, upsample=True, bias=P[un + ".bias"])
+    assert (Ho, Wo) == (512, 512)
+    y = _nchw(y, 1, 512, 512)
+    e_bf, e_32, theirs = rel(y, refbf), rel(y, ref32), rel(refbf, ref32)
+    print("vae up block: HIP vs oracle-bf16 %.3e | vs oracle-fp32 %.3e | oracle bf16 vs fp32 %.3e" % (e_bf, e_32, theirs))
+    assert e_bf < 1e-2 and e_32 <= 1.5 * theirs + 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # (d) bf16 ContinuousLVLM.generate vs the reference's own bf16 CPU run
 # ---------------------------------------------------------------------------------------------------------------------
 class _Tok:
@@ -332,6 +437,10 @@ class _Tok:
         self.ids = ids
 
     def encode(self, s, add_special_tokens=False):
+        if s == "<img>":
+            return [self.ids[0]]
+        if s == "</img>":
+            return [self.ids[-1]]
         return list(self.ids)
 
     def decode(self, ids, skip_special_tokens=False):

@@ -1,7 +1,12 @@
 """GPU parity of the SDXL de-tokenizer half (conv3x3 implicit GEMM, GroupNorm, GEGLU, UNet, VAE decoder,
-Euler/CFG pipeline, ResamplerXLV2, SDXLAdapter.generate) against the CPU oracle (oracle/sdxl_oracle.py —
-restatement of the published diffusers semantics; parity unpinned at that boundary) on tiny configs, in
-fp32 (gate: 2e-4 relative) and bf16 (5e-2 relative: GroupNorm statistics / 3x3 convs in bf16 inputs)."""
+Euler/CFG pipeline, ResamplerXLV2, SDXLAdapter.generate) against the CPU oracle (oracle/sdxl_oracle.py — an
+independent restatement of the published diffusers semantics; parity unpinned at that boundary).
+
+fp32 mode: 2e-4 relative on whole tiny networks.  bf16 mode: a whole network in bf16 is a chaotic function of its
+roundings (the oracle's OWN bf16 run — same rounding points: one torch bf16 op per module — sits 1-2e-2 from its fp32
+run), so the bf16 gates are (i) distance to the bf16 oracle <= 3e-2 and (ii) distance to the fp32 oracle no larger
+than 1.5x the bf16 oracle's own distance to it (+2e-3); single full-size blocks (tests/test_fulldim_gpu.py) are
+shallow enough for 1e-2."""
 import math
 
 import pytest
@@ -55,7 +60,7 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
-@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39])
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
 def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
@@ -86,7 +91,7 @@ def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
         assert torch.equal(other, y)
 
 
-@pytest.mark.parametrize("cfg", [33, 36, 38, 39])
+@pytest.mark.parametrize("cfg", [33, 36, 38, 39, 40, 43])
 def test_conv3x3_persistent_multi_tile(cfg):
     """Implicit-GEMM conv through the persistent configurations with > 1 output tile per workgroup."""
     from seedstory import _lib, ops
@@ -165,8 +170,15 @@ def _unet(dtype):
     return m.to(DEV, dtype), wd, c
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
-def test_unet_forward_tiny(dtype, tol):
+def _bf16_gates(y, ref32, refbf, what):
+    ours_bf, ours_32, theirs = rel(y, refbf), rel(y, ref32), rel(refbf, ref32)
+    print("%s bf16: HIP vs oracle-bf16 %.3e | HIP vs oracle-fp32 %.3e | oracle bf16 vs fp32 %.3e" % (what, ours_bf, ours_32, theirs))
+    assert ours_bf < 3e-2
+    assert ours_32 <= 1.5 * theirs + 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_forward_tiny(dtype):
     m, wd, c = _unet(dtype)
     x = synth.normal_like(5, (2, 4, 16, 16), 1.0)
     ctx = synth.normal_like(6, (2, 8, 128), 1.0)
@@ -175,11 +187,17 @@ def test_unet_forward_tiny(dtype, tol):
     ref = S.unet_forward(wd, c, x, torch.tensor(801.0), ctx, pooled, tid)
     y = m(x.to(DEV, dtype), 801.0, ctx.to(DEV, dtype), added_cond_kwargs={"text_embeds": pooled.to(DEV, dtype), "time_ids": tid}).sample
     assert y.shape == ref.shape
-    assert rel(y, ref) < tol
+    if dtype == torch.float32:
+        assert rel(y, ref) < 2e-4
+    else:
+        bf = torch.bfloat16
+        refbf = S.unet_forward({k: v.to(bf) for k, v in wd.items()}, c, x.to(bf), torch.tensor(801.0), ctx.to(bf),
+                               pooled.to(bf), tid)
+        _bf16_gates(y, ref, refbf, "tiny UNet")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
-def test_vae_decode_tiny(dtype, tol):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vae_decode_tiny(dtype):
     from seedstory.diffusion import AutoencoderKL
     c = S.TINY_VAE
     wd = S.synth_weights(S.vae_decoder_shapes(c), 2)
@@ -190,7 +208,12 @@ def test_vae_decode_tiny(dtype, tol):
     lat = synth.normal_like(20, (1, 4, 12, 12), 1.0)
     ref = S.vae_decode(wd, c, lat)
     y = m.decode((lat / c["scaling_factor"]).to(DEV, dtype)).sample
-    assert rel(y, ref) < tol
+    if dtype == torch.float32:
+        assert rel(y, ref) < 2e-4
+    else:
+        bf = torch.bfloat16
+        refbf = S.vae_decode({k: v.to(bf) for k, v in wd.items()}, c, lat.to(bf))
+        _bf16_gates(y, ref, refbf, "tiny VAE")
 
 
 def test_vae_mid_attention_wide_head_path():
@@ -308,6 +331,55 @@ def test_resampler_xlv2(golden):
     ctx, pooled = m(g["xlv2.x"].to(DEV))
     assert rel(ctx, g["xlv2.ctx"]) < 1e-4
     assert rel(pooled, g["xlv2.pooled"]) < 1e-4
+
+
+def test_sdxl_adapter_get_image_embeds_numeric(golden):
+    """a14: SDXLAdapter.get_image_embeds(image_embeds=...) (adapter_modules.py:387-428) — positive feature and the
+    hoisted all-zeros-image feature, concatenated [pos; neg], through ResamplerXLV2, chunk(2) — against the oracle built
+    from the golden-pinned ViT / ResamplerXLV2 restatements; also the image_tensor path and a 2-image batch."""
+    from src.models.discrete_models import DiscreteModleIdentity
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    from src.models_ipa.adapter_modules import SDXLAdapter
+    from src.models_ipa.resampler import ResamplerXLV2
+    g, meta = golden
+    cv, cx = meta["VIT"], meta["XLV2"]
+    vwd = synth.vit_weights(31, cv["width"], cv["layers"], cv["heads"], cv["mlp_width"], cv["patch"], cv["out_dim"],
+                            cv["n_queries"])
+    xwd = synth.resampler_xlv2_weights(41, **cx)
+    vit = VisionTransformerWithAttnPool(image_size=cv["image"], patch_size=cv["patch"], width=cv["width"],
+                                        layers=cv["layers"], heads=cv["heads"], mlp_ratio=cv["mlp_width"] / cv["width"],
+                                        n_queries=cv["n_queries"], output_dim=cv["out_dim"])
+    assert not any(vit.load_state_dict(vwd, strict=False))
+    rs = ResamplerXLV2(**cx)
+    assert not any(rs.load_state_dict(xwd, strict=False))
+    adapter = SDXLAdapter.from_pretrained(unet=None, resampler=rs).to(DEV).eval()
+    adapter.init_pipe(vae=None, scheduler=None, visual_encoder=vit, image_transform=None,
+                      discrete_model=DiscreteModleIdentity(), dtype=torch.float32, device=DEV)
+    vkw = dict(width=cv["width"], layers=cv["layers"], heads=cv["heads"], patch=cv["patch"], out_dim=cv["out_dim"],
+               n_queries=cv["n_queries"])
+    feat_neg = O.vit_forward(vwd, torch.zeros(1, 3, cv["image"], cv["image"]), **vkw)          # :406-414
+    # (1) regressed-feature path, one image (what generate() uses)
+    feat = synth.normal_like(77, (1, cv["n_queries"], cv["out_dim"]), 1.0)
+    ref = S.adapter_image_embeds(xwd, cx, feat, feat_neg)
+    got = adapter.get_image_embeds(image_embeds=feat.to(DEV), image_size=cv["image"])
+    for a, b, name in zip(got, ref, ("ctx_pos", "ctx_neg", "pooled_pos", "pooled_neg")):
+        assert a.shape == b.shape and rel(a, b) < 1e-4, name
+    # a second call hits the cached negative branch: identical
+    got2 = adapter.get_image_embeds(image_embeds=feat.to(DEV), image_size=cv["image"])
+    assert all(torch.equal(a, b) for a, b in zip(got, got2))
+    # (2) image_tensor path: [img; zeros] through the ViT together (:399-404)
+    img = synth.normal_like(78, (1, 3, cv["image"], cv["image"]), 1.0)
+    ref_t = S.adapter_image_embeds(xwd, cx, O.vit_forward(vwd, img, **vkw), feat_neg)
+    got_t = adapter.get_image_embeds(image_tensor=img.to(DEV))
+    for a, b in zip(got_t, ref_t):
+        assert rel(a, b) < 1e-4
+    # (3) two stories rendered together: image b of the batch equals its own single call
+    feat2 = synth.normal_like(79, (2, cv["n_queries"], cv["out_dim"]), 1.0)
+    gb = adapter.get_image_embeds(image_embeds=feat2.to(DEV), image_size=cv["image"])
+    for b in range(2):
+        single = S.adapter_image_embeds(xwd, cx, feat2[b:b + 1], feat_neg)
+        for a, r in zip(gb, single):
+            assert rel(a[b:b + 1], r) < 1e-4
 
 
 def test_sdxl_adapter_generate_tiny():
