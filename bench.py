@@ -109,6 +109,19 @@ class Story:
         return cap + IMG_IDS + [EOS]
 
 
+def advance_context(st, forced_ids, new_feat):
+    """Context bookkeeping of one finished step on token ids (gen_george.py:224-243 does it on strings)."""
+    st.image_embeds = torch.cat([st.image_embeds, new_feat], dim=0)       # gen_george.py:224
+    st.ids = st.ids + list(forced_ids[:CAPTION]) + IMG_IDS                # prompt + text + image_tokens (:231)
+    st.evicted_last = False
+    while st.image_embeds.shape[0] > WINDOW:                              # :235-239: cut through the first </img>,
+        e = st.ids.index(IMG_IDS[-1])                                     # drop the oldest image, re-add BOS (:243)
+        st.ids = [BOS] + st.ids[e + 1:]
+        st.image_embeds = st.image_embeds[1:]
+        st.evicted_last = True
+    st.step += 1
+
+
 def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
     """The MLLM half of one multimodal step of every resident story (slot b of the engine = story sts[b]; all
     stories of a round are at the same step index): ``agent.generate`` of gen_george.py:189/257.  Advances the
@@ -143,15 +156,7 @@ def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
     feats = torch.stack([eng.select(b).hidden_rows[e - 64:e] for b in range(len(sts))]).contiguous()   # models.py:197
     img_gen_feat = rout(feats)                                            # models.py:205  [S,256,4096]
     for b, st in enumerate(sts):
-        st.image_embeds = torch.cat([st.image_embeds, img_gen_feat[b:b + 1]], dim=0)   # gen_george.py:224
-        st.ids = st.ids + forced[b][:CAPTION] + IMG_IDS                   # prompt + text + image_tokens (:231)
-        st.evicted_last = False
-        while st.image_embeds.shape[0] > WINDOW:                          # :235-239: cut through the first </img>,
-            e = st.ids.index(IMG_IDS[-1])                                 # drop the oldest image, re-add BOS (:243)
-            st.ids = [BOS] + st.ids[e + 1:]
-            st.image_embeds = st.image_embeds[1:]
-            st.evicted_last = True
-        st.step += 1
+        advance_context(st, forced[b], img_gen_feat[b:b + 1])
     return img_gen_feat
 
 

@@ -199,3 +199,118 @@ def test_pipeline_stable_conditioning_buffers():
     assert b3.data_ptr() != ptr and b3.shape == (3, 6)
     other = pipe._stable("pooled", a)
     assert other.data_ptr() not in (ptr, b3.data_ptr())
+
+
+_RING_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SS_PKG"]); sys.path.insert(0, os.environ["SS_ROOT"])
+from seedstory import parallel as P
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+# ---- (1) the scheduling code with a stub engine: a KV slab grown 5 rows per round FROM THE MIRROR's previous rows ----
+class Stub(P.SlotRingBackend):
+    def __init__(self):
+        self.k = torch.zeros(2, 2, 64, 4); self.ctx = []; self.rendered = []; self.applied = []
+    def mllm_round(self, r):
+        lo, hi = 5 * r, 5 * r + 5
+        prev = float(self.k[:, :, :lo].sum())                 # depends on every earlier round being mirrored correctly
+        self.k[:, :, lo:hi] = prev * 0.5 + r + 1 + torch.arange(5).view(1, 1, 5, 1)
+        self.ctx.append(r * 7 + 1)
+        return [lo, hi, r * 7 + 1], [self.k[:, :, lo:hi].contiguous()]
+    def alloc(self, meta):
+        return [torch.empty(2, 2, meta[1] - meta[0], 4)]
+    def apply(self, r, meta, tensors):
+        self.k[:, :, meta[0]:meta[1]] = tensors[0]; self.ctx.append(meta[2]); self.applied.append(r)
+    def render(self, r, meta, tensors):
+        import time; time.sleep(0.05)                          # slower than an MLLM round: later rounds must not wait for it
+        self.rendered.append((r, float(tensors[0].sum())))
+
+n = 7
+be = Stub()
+mine = P.run_slot_ring(be, n, rank, world)
+ref = Stub()                                                    # single-process reference: every round computed locally
+for r in range(n):
+    ref.mllm_round(r)
+assert mine == [r for r in range(n) if r % world == rank], mine
+assert torch.equal(be.k, ref.k) and be.ctx == ref.ctx
+assert [r for r, _ in be.rendered] == mine and sorted(be.applied + mine) == list(range(n))
+
+# ---- (2) StoryRingBackend (payload / mirror logic of the real bench schedule) over a fake engine ----------------------
+import bench as bm
+bm.STORY_LEN, bm.WINDOW = 6, 3                                   # evictions at steps 3, 4, 5; new stories after step 5
+HID = 8
+class FakeEng:
+    n_layers, n_heads, hd, hidden = 2, 2, 4, HID
+    def __init__(self, n_seq):
+        self.K = [torch.zeros(2, 2, 1024, 4) for _ in range(n_seq)]; self.V = [torch.zeros(2, 2, 1024, 4) for _ in range(n_seq)]
+        self.cur = 0
+    def select(self, b): self.cur = b; return self
+    @property
+    def k_cache(self): return self.K[self.cur]
+    @property
+    def v_cache(self): return self.V[self.cur]
+def row_val(seed, ids, row, gen):                               # value of KV row `row`: depends on the token sitting there
+    tok = ids[row] if row < len(ids) else gen[row - len(ids)]
+    return float((seed * 31 + row * 7 + tok * 13) % 1009)
+def fake_mllm_part(sts, eng, rin, rout, vit, kv_reuse):
+    feats = []
+    for b, st in enumerate(sts):
+        eng.select(b)
+        if st.step == 0:
+            st.image_embeds = torch.full((1, 256, HID), float(st.seed % 97))
+        S = len(st.ids)
+        keep = S - 65 if (st.step > 0 and not st.evicted_last) else 0
+        for row in range(keep):                                 # the mirror must already hold the rows being reused
+            assert float(eng.k_cache[0, 0, row, 0]) == row_val(st.seed, st.ids, row, []), (rank, b, st.step, row)
+        st._S, st._keep = S, keep
+    forced = [st.forced() for st in sts]
+    for b, st in enumerate(sts):
+        eng.select(b)
+        for row in range(st._keep, st._S + 114):
+            val = row_val(st.seed, st.ids, row, forced[b])
+            eng.k_cache[:, :, row] = val; eng.v_cache[:, :, row] = val + 0.5
+        feats.append(torch.full((256, HID), float((st.seed + st.step) % 89)))
+    feat = torch.stack(feats)
+    for b, st in enumerate(sts):
+        bm.advance_context(st, forced[b], feat[b:b + 1])
+    return feat
+bm.mllm_part = fake_mllm_part
+_orig_init = bm.Story.__init__
+def _init(self, seed, device):
+    _orig_init(self, seed, device); self.seed = seed
+bm.Story.__init__ = _init
+def run(world_, rank_, rounds):
+    be = P.StoryRingBackend(bm, FakeEng(2), None, None, None, None, 2, "cpu", torch.float32, 30)
+    P.run_slot_ring(be, rounds, rank_, world_)
+    return be
+rounds = 9                                                       # crosses the story boundary (6) and several evictions
+be = run(world, rank, rounds)
+bm2_ref = P.StoryRingBackend(bm, FakeEng(2), None, None, None, None, 2, "cpu", torch.float32, 30)
+for r in range(rounds):
+    bm2_ref.mllm_round(r)                                        # single-process reference of the same stream
+for b in range(2):
+    a, c = be.sts[b], bm2_ref.sts[b]
+    assert a.ids == c.ids and a.step == c.step and a.evicted_last == c.evicted_last and torch.equal(a.image_embeds, c.image_embeds)
+    S = len(a.ids)
+    keep = S - 65 if not a.evicted_last else 0                  # what the NEXT round would reuse must be mirrored
+    assert torch.equal(be.eng.K[b][:, :, :keep], bm2_ref.eng.K[b][:, :, :keep]) and torch.equal(be.eng.V[b][:, :, :keep], bm2_ref.eng.V[b][:, :, :keep])
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_slot_ring_world_size_2_gloo(tmp_path):
+    """The multi-GPU slot ring (north_star: image slots sharded over the GPUs, MLLM KV cache broadcast): (1) the
+    scheduling code of run_slot_ring with a stub engine, (2) StoryRingBackend's payload / mirror bookkeeping (KV row
+    ranges, eviction re-prefill, story boundaries) over a fake engine whose MLLM round ASSERTS that the rows it
+    reuses were mirrored — two gloo ranks vs a single-process reference of the same stream."""
+    script = tmp_path / "ring.py"
+    script.write_text(_RING_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SS_PKG=PKG, SS_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
