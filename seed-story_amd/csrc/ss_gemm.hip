@@ -367,7 +367,7 @@ template <> int gemm_sp_dispatch<float>(int, const GemmArgs&, hipStream_t) { ret
 template <> int gemm_sp_dispatch_conv<float>(int, const GemmArgs&, hipStream_t) { return 1; }
 
 // cfg ids: 1-3 register-staged, 8/10/15 double-buffered LDS-DMA (any K % 8 == 0, ragged tiles through a zero page),
-// 20-46 software-pipelined LDS-DMA (ss_gemm_sp.inc; K % 64 == 0) with the double-buffered kernel of the nearest tile
+// 20-52 software-pipelined / role-split LDS-DMA (ss_gemm_sp.inc; K % 64 == 0) with the double-buffered kernel of the nearest tile
 // as their fallback for ineligible shapes.
 template <typename T>
 static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
@@ -462,7 +462,7 @@ __global__ void tune_fill_kernel(uint16_t* p, size_t n, uint32_t seed, int is_bf
 }
 
 static const int kTuneCands[] = {8, 15, 10, 20, 21, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
-                                 40, 41, 42, 43, 44, 45, 46};
+                                 40, 41, 42, 43, 44, 45, 46, 50, 51, 52};
 
 template <typename T>
 static int tune_shape(GemmArgs g, void* ws, size_t ws_bytes, size_t a_elems, hipStream_t s, float* best_us) {

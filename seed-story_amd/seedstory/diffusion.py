@@ -296,6 +296,7 @@ class UNet2DConditionModel(nn.Module):
                 P["temb_all.offsets"][n] = off
                 off += sd[n + ".time_emb_proj.weight"].shape[0]
         self._prep, self._prep_sig = P, sig
+        self._prep_gen = getattr(self, "_prep_gen", 0) + 1      # identity of the prepared weights (graph cache key)
         return P
 
     # -- forward ----------------------------------------------------------------------------------------------
@@ -335,6 +336,7 @@ class UNet2DConditionModel(nn.Module):
                     if not hasattr(self, "_ctx_kv_buf"):
                         self._ctx_kv_buf = {}
                     buf = self._ctx_kv_buf[b] = torch.empty(ctx2d.shape[0], w.shape[0], dtype=ctx2d.dtype, device=ctx2d.device)
+                    self._kv_gen = getattr(self, "_kv_gen", 0) + 1      # a captured forward holding the old address is stale
                 kv = self._ctx_kv[b] = ops.gemm(ctx2d, w, out=buf)
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
             h = ops.gemm(a, P[b + ".attn2.to_out.0.weight"], bias=P[b + ".attn2.to_out.0.bias"], residual=h)
@@ -422,14 +424,20 @@ class _VaeConfig:
 
 
 class AutoencoderKL(nn.Module):
-    """Decoder half only (the story path never encodes).  Runs in the module dtype: bf16 has the
-    range fp16 lacked, so diffusers' fp32 ``force_upcast`` of the fp16 VAE is not needed."""
+    """Decoder half only (the story path never encodes).
+
+    Decode precision (diffusers: the SDXL VAE config sets ``force_upcast`` and the pipeline decodes an fp16 VAE in
+    fp32, because its activations overflow fp16 at 1024 px — gen_george.py:62 + StableDiffusionXLPipeline):
+      * bf16 module -> bf16 decode (fp32's exponent range: no overflow; tests/test_fulldim_gpu.py::
+        test_vae_decode_full_size_pixel_parity measures the uint8 deviation from the fp32 reference);
+      * fp16 module with ``force_upcast`` (the reference's default dtype) -> decoded in **bf16**, never in fp16;
+      * ``set_tuning("vae_fp32", 1)`` -> decoded in fp32 (exact-fp32 MFMA path: the reference's arithmetic, ~8x slower)."""
 
     def __init__(self, config=None):
         super().__init__()
         self.cfg = dict(SDXL_BASE_VAE if config is None else config)
         _grow(self, _vae_shapes(self.cfg))
-        self.config = _VaeConfig(self.cfg["scaling_factor"])
+        self.config = _VaeConfig(self.cfg["scaling_factor"], bool(self.cfg.get("force_upcast", True)))
         self._prep = None
         self._prep_sig = None
 
@@ -440,7 +448,8 @@ class AutoencoderKL(nn.Module):
             jc = json.load(f)
         cfg = dict(latent_channels=jc.get("latent_channels", 4), out_channels=jc.get("out_channels", 3),
                    block_out_channels=tuple(jc["block_out_channels"]), layers_per_block=jc.get("layers_per_block", 2),
-                   norm_groups=jc.get("norm_num_groups", 32), scaling_factor=jc.get("scaling_factor", 0.13025))
+                   norm_groups=jc.get("norm_num_groups", 32), scaling_factor=jc.get("scaling_factor", 0.13025),
+                   force_upcast=jc.get("force_upcast", True))
         m = cls(cfg)
         from safetensors.torch import load_file
         sd = {}
@@ -459,13 +468,23 @@ class AutoencoderKL(nn.Module):
         self._prep = None
         return self
 
-    def _prepare(self):
-        sig = _sig(self)
+    def decode_dtype(self):
+        """Arithmetic dtype of the decoder for this module's parameter dtype (see the class docstring)."""
+        p0 = next(self.parameters()).dtype
+        if _lib.get_tuning("vae_fp32", 0):
+            return torch.float32
+        if p0 == torch.float16 and self.config.force_upcast:
+            return torch.bfloat16
+        return p0
+
+    def _prepare(self, run_dtype=None):
+        run_dtype = self.decode_dtype() if run_dtype is None else run_dtype
+        sig = _sig(self) + (run_dtype,)
         if self._prep is not None and self._prep_sig == sig:
             return self._prep
         P = {}
         for k, v in self.named_parameters():
-            v = v.data
+            v = v.data.to(run_dtype)
             if v.dim() == 4 and v.shape[-1] == 3:
                 P[k] = _conv_w(v, 8 if v.shape[1] < 8 else None)
             elif v.dim() == 4:
@@ -497,10 +516,11 @@ class AutoencoderKL(nn.Module):
         """latents [B,4,h,w] (times `prescale`, i.e. pass 1/scaling_factor for raw latents) -> NHWC image
         tensor [B*H*W, 8] in [-1,1] (channels 3..7 are zero padding)."""
         c = self.cfg
-        P = self._prepare()
+        run_dtype = self.decode_dtype()
+        P = self._prepare(run_dtype)
         G, boc = c["norm_groups"], c["block_out_channels"]
         B, _, H, W = latents_scaled.shape
-        z = ops.nchw_to_nhwc(latents_scaled.contiguous(), 8)
+        z = ops.nchw_to_nhwc(latents_scaled.to(run_dtype).contiguous(), 8)
         pq = P["post_quant_conv.weight"]
         if prescale != 1.0:
             key = "post_quant_conv.weight@%r" % prescale
@@ -551,7 +571,7 @@ class AutoencoderKL(nn.Module):
         """diffusers signature: latents are ALREADY divided by scaling_factor by the caller."""
         img, H, W = self.decode_nhwc(latents)
         B = latents.shape[0]
-        out = ops.nhwc_to_nchw(img, B, self.cfg["out_channels"], H, W)
+        out = ops.nhwc_to_nchw(img, B, self.cfg["out_channels"], H, W).to(latents.dtype)
         return _Sample(out) if return_dict else (out,)
 
 
@@ -622,6 +642,10 @@ class StableDiffusionXLPipeline:
         cur = bufs.get(name)
         if cur is None or cur.shape != value.shape or cur.dtype != value.dtype or cur.device != value.device:
             cur = bufs[name] = value.contiguous().clone()
+            # captured forwards read the OLD buffer: they can never be replayed again (and the caching allocator may hand
+            # its address to an unrelated tensor) -> drop them, their private pools with them
+            self._buf_gen = getattr(self, "_buf_gen", 0) + 1
+            self.__dict__.get("_graphs", {}).clear()
         else:
             cur.copy_(value)
         return cur
@@ -631,8 +655,12 @@ class StableDiffusionXLPipeline:
         replayed for steps 1..n-1 of every render: removes the per-launch gaps (~5 % of a forward at batch 8, ~10 %
         at batch 2).  Returns None (eager fallback) if capture is not possible."""
         graphs = self.__dict__.setdefault("_graphs", {})
-        key = (tuple(xin.shape), xin.dtype, ctx.data_ptr(), cond["text_embeds"].data_ptr(),
-               tuple(cond["time_ids"].flatten().tolist()), id(self.unet._prep))
+        # identity = shapes + GENERATION counters of every buffer the captured launches read (conditioning buffers,
+        # per-block cross-attention K/V buffers, prepared weights) — never raw addresses or id(): those are reused
+        key = (tuple(xin.shape), xin.dtype, tuple(ctx.shape), tuple(cond["time_ids"].flatten().tolist()),
+               getattr(self, "_buf_gen", 0), getattr(self.unet, "_kv_gen", 0), getattr(self.unet, "_prep_gen", 0))
+        for k_old in [k for k in graphs if k[4:] != key[4:]]:      # entries of an older generation are dead
+            del graphs[k_old]
         ent = graphs.get(key)
         table = timestep_embedding(torch.as_tensor(ts, dtype=torch.float32), self.unet.cfg["block_out_channels"][0])
         table = table.to(device=xin.device, dtype=xin.dtype)[:, None, :].expand(-1, xin.shape[0], -1).contiguous()

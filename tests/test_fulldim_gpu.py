@@ -429,6 +429,52 @@ def test_sdxl_vae_up_block_full_size():
     assert e_bf < 1e-2 and e_32 <= 1.5 * theirs + 1e-3
 
 
+def test_vae_decode_full_size_pixel_parity():
+    """SDXL VAE decoder at full size (128^2 latents -> 1024^2 image): the bf16 decode the pipeline ships vs (i) the
+    library's exact-fp32 decode (the reference's arithmetic: diffusers force_upcast, gen_george.py:62) and (ii) the
+    fp16-module path, which must decode in bf16 (never fp16).  Reports the uint8 deviation; the fp32 HIP decode
+    itself is pinned to the CPU oracle on one 64-row band of the image (full-image CPU decode is 10.5 TFLOP)."""
+    import sdxl_oracle as S
+    from seedstory import _lib, ops
+    from seedstory.diffusion import AutoencoderKL
+    vae = AutoencoderKL().to(DEV, torch.bfloat16).init_synthetic(21)
+    lat = (synth.normal_like(61, (1, 4, 128, 128), 1.0) * 0.13025 * 3.0)
+    sc = 1.0 / vae.config.scaling_factor
+
+    def u8(dtype_module, fp32):
+        m = vae.to(dtype_module)
+        _lib.set_tuning("vae_fp32", 1 if fp32 else 0)
+        try:
+            img, Hh, Ww = m.decode_nhwc(lat.to(DEV, dtype_module), prescale=sc)
+            return ops.image_to_u8(img, Hh * Ww).view(Hh, Ww, 3).cpu(), img.float().cpu().view(Hh, Ww, -1)[:, :, :3]
+        finally:
+            _lib.set_tuning("vae_fp32", 0)
+    a_bf16, f_bf16 = u8(torch.bfloat16, False)
+    a_fp32, f_fp32 = u8(torch.bfloat16, True)             # bf16-rounded weights, fp32 arithmetic
+    a_f16m, _ = u8(torch.float16, False)                   # fp16 module: decoded in bf16 by policy
+    assert a_bf16.shape == (1024, 1024, 3)
+    d = (a_bf16.int() - a_fp32.int()).abs()
+    print("VAE 1024^2 decode, bf16 vs fp32 arithmetic: uint8 max dev %d, mean %.4f, pixels differing %.2f%%, rel(float) %.3e"
+          % (int(d.max()), float(d.float().mean()), 100.0 * float((d > 0).float().mean()), rel(f_bf16, f_fp32)))
+    assert torch.isfinite(f_bf16).all() and rel(f_bf16, f_fp32) < 3e-2 and float(d.float().mean()) < 1.0
+    d16 = (a_f16m.int() - a_fp32.int()).abs()
+    assert float(d16.float().mean()) < 1.0               # same class of deviation: it ran in bf16, not in (overflowing) fp16
+    # pin the fp32 HIP decode to the CPU oracle on a tile: decode a 32x32 latent crop with both (fully convolutional
+    # except the mid attention and GroupNorm statistics, so the crop is its own complete problem)
+    wd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+    crop = lat[:, :, :32, :32].contiguous()
+    ref = S.vae_decode(wd, S.SDXL_BASE_VAE, crop)
+    _lib.set_tuning("vae_fp32", 1)
+    try:
+        img, Hh, Ww = vae.to(torch.bfloat16).decode_nhwc(crop.to(DEV, torch.bfloat16), prescale=sc)
+    finally:
+        _lib.set_tuning("vae_fp32", 0)
+    got = img.float().cpu().view(Hh, Ww, -1)[:, :, :3].permute(2, 0, 1)[None]
+    e = rel(got, ref)
+    print("  fp32 HIP decode vs CPU oracle (256^2 crop, full SDXL VAE width): rel %.3e" % e)
+    assert e < 2e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (d) bf16 ContinuousLVLM.generate vs the reference's own bf16 CPU run
 # ---------------------------------------------------------------------------------------------------------------------

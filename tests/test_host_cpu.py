@@ -314,3 +314,43 @@ def test_slot_ring_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_pipeline_graph_cache_dies_with_its_buffers():
+    """a captured UNet forward must never be matched again once a buffer it reads was reallocated (batch
+    1 -> 4 -> 1): reallocation bumps a generation counter and drops every cached graph."""
+    import torch
+    from seedstory.diffusion import StableDiffusionXLPipeline
+    pipe = StableDiffusionXLPipeline(vae=None, unet=None, scheduler=None)
+    pipe._stable("ctx", torch.zeros(2, 6))
+    g0 = pipe._buf_gen
+    pipe._graphs = {"some-key": object()}
+    pipe._stable("ctx", torch.ones(2, 6))                 # same shape: in place, graphs stay
+    assert pipe._buf_gen == g0 and len(pipe._graphs) == 1
+    pipe._stable("ctx", torch.zeros(8, 6))                # new batch: new storage
+    assert pipe._buf_gen == g0 + 1 and pipe._graphs == {}
+    pipe._graphs = {"k": 1}
+    pipe._stable("ctx", torch.zeros(2, 6))                # back to the first shape: again a NEW buffer, never the old one
+    assert pipe._buf_gen == g0 + 2 and pipe._graphs == {}
+
+
+def test_vae_decode_dtype_policy():
+    """ADVICE r1: the fp16 SDXL VAE is never decoded in fp16 (diffusers upcasts it: force_upcast); bf16 stays bf16;
+    vae_fp32 selects the reference's fp32 arithmetic."""
+    import torch
+    from seedstory import _lib
+    from seedstory.diffusion import AutoencoderKL
+    cfg = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
+               norm_groups=32, scaling_factor=0.13025)
+    v = AutoencoderKL(cfg)
+    assert v.config.force_upcast is True
+    assert v.to(torch.float16).decode_dtype() == torch.bfloat16
+    assert v.to(torch.bfloat16).decode_dtype() == torch.bfloat16
+    assert v.to(torch.float32).decode_dtype() == torch.float32
+    v2 = AutoencoderKL(dict(cfg, force_upcast=False)).to(torch.float16)
+    assert v2.decode_dtype() == torch.float16
+    _lib.set_tuning("vae_fp32", 1)
+    try:
+        assert v.to(torch.float16).decode_dtype() == torch.float32
+    finally:
+        _lib.set_tuning("vae_fp32", 0)

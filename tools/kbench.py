@@ -113,19 +113,22 @@ def cmd_attn():
         v = torch.randn(B, L, E, device=DEV, dtype=dt)
         row = {"B": B, "heads": Hh, "hd": hd, "L": L, "causal": causal}
         flops = 4.0 * B * Hh * L * L * hd * (0.5 if causal else 1.0)
-        for ver in (2, 3, 4):
+        for ver, xcd in ((2, 0), (3, 0), (3, 1)):
             _lib.set_tuning("attn_ver", ver)
+            _lib.set_tuning("attn_xcd", xcd)
             us = min(timed(lambda: ops.attention(q, k, v, Hh, None, causal), n=8) for _ in range(3))
-            row["v%d_us" % ver] = round(us, 1)
-            row["v%d_tflops" % ver] = round(flops / (us * 1e-6) / 1e12, 1)
+            tag = "v%d%s" % (ver, "x" if xcd else "")
+            row[tag + "_us"] = round(us, 1)
+            row[tag + "_tflops"] = round(flops / (us * 1e-6) / 1e12, 1)
         _lib.set_tuning("attn_ver", 3)
+        _lib.set_tuning("attn_xcd", 1)
         res.append(row)
         print(row)
     json.dump(res, open(os.path.join(OUT, "attn_ab.json"), "w"), indent=0)
 
 
 def cmd_unet(UB):
-    from seedstory.diffusion import AutoencoderKL, UNet2DConditionModel
+    from seedstory.diffusion import UNet2DConditionModel
     dt = torch.bfloat16
     unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
     x = torch.randn(UB, 4, 128, 128, device=DEV, dtype=dt)
@@ -137,13 +140,20 @@ def cmd_unet(UB):
     ops.softmax_rows_(torch.zeros(1, 8, device=DEV, dtype=dt), 1.0)   # marker kernel for tools/trace_summary.py
     us = timed(lambda: unet(x, 500.0, ctx, added_cond_kwargs=cond), n=3, warm=0)
     out = {"unet_batch": UB, "forward_ms_eager": round(us / 1e3, 2), "tflops": round(UB * 6.747e12 / (us * 1e-6) / 1e12, 1)}
+    print(out)
+    json.dump(out, open(os.path.join(OUT, "unet_time_b%d.json" % UB), "w"))
+
+
+def cmd_vae():
+    from seedstory.diffusion import AutoencoderKL
+    dt = torch.bfloat16
     vae = AutoencoderKL().to(DEV, dt).init_synthetic(2)
     lat = torch.randn(1, 4, 128, 128, device=DEV, dtype=dt) * 0.5
     vae.decode_nhwc(lat, prescale=1.0 / 0.13025)
     usv = timed(lambda: vae.decode_nhwc(lat, prescale=1.0 / 0.13025), n=3, warm=0)
-    out["vae_decode_ms"] = round(usv / 1e3, 2)
+    out = {"vae_decode_ms": round(usv / 1e3, 2)}
     print(out)
-    json.dump(out, open(os.path.join(OUT, "unet_time_b%d.json" % UB), "w"))
+    json.dump(out, open(os.path.join(OUT, "vae_time.json"), "w"))
 
 
 if __name__ == "__main__":
@@ -157,3 +167,5 @@ if __name__ == "__main__":
         cmd_attn()
     elif cmd == "unet":
         cmd_unet(batch)
+    elif cmd == "vae":
+        cmd_vae()
