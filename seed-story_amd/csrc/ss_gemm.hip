@@ -374,7 +374,7 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
     if (cfg >= 20 && Tr<T>::kVec == 8) {
         const int rc = g.conv_Cin > 0 ? gemm_sp_dispatch_conv<T>(cfg, g, s) : gemm_sp_dispatch<T>(cfg, g, s);
         if (rc <= 0) return rc;
-        cfg = (cfg == 21) ? 15 : (cfg == 22 || cfg == 29) ? 10 : 8;
+        cfg = (cfg == 21 || cfg == 68) ? 15 : (cfg == 22 || cfg == 29 || cfg == 67) ? 10 : 8;
     }
     switch (cfg) {
         case 1: return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
@@ -462,7 +462,7 @@ __global__ void tune_fill_kernel(uint16_t* p, size_t n, uint32_t seed, int is_bf
 }
 
 static const int kTuneCands[] = {8, 15, 10, 20, 21, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
-                                 40, 41, 42, 43, 44, 45, 46, 50, 51, 52};
+                                 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69};
 
 template <typename T>
 static int tune_shape(GemmArgs g, void* ws, size_t ws_bytes, size_t a_elems, hipStream_t s, float* best_us) {

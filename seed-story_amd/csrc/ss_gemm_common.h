@@ -9,6 +9,8 @@
 // tile (rows -> n) and the "B" operand the ACTIVATION tile (cols -> m), so a lane ends up with
 // C[m = l&15][n = 4*(l>>4) .. +3]: four consecutive n per row.
 #pragma once
+#include <type_traits>
+
 #include "ss_common.h"
 
 namespace ss {
@@ -236,6 +238,101 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LDS-staged epilogue for 16-bit outputs.  The direct epilogue above stores 8 bytes per lane with the 16 lanes of a
+// group on 16 different rows: every store instruction touches 16 cache lines with a 32-byte piece each (4-byte pieces
+// with GEGLU), and the residual is read the same way — store-ISSUE-bound: ~15 us of fixed cost per 256x256 tile against
+// 1.5 us per K tile, i.e. a third of a K = 1280 GEMM.  Here a wave transposes its fragments through a PRIVATE LDS
+// strip (CR rows at a time; no barrier: one wave's LDS operations execute in order) and then moves whole rows: every
+// lane stores 16 contiguous bytes and a store instruction covers full lines; bias / GELU / time-embedding are applied
+// before staging (value rounded to T exactly where the direct path rounds it), the residual is added on the coalesced
+// read-back.  Requirements (checked by the caller): the wave's TM x TN sub-tile lies inside [M, N) in N (rows are
+// masked), C / residual 16-byte aligned with ldc / ldr % 8 == 0.
+template <typename T, int FM, int FN, int CR>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
+                                                     int lane, char* stg) {
+    static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
+    constexpr int TN = FN * 16, TMw = FM * 16;
+    constexpr int FPC = CR / 16;                       // M fragments per chunk
+    static_assert(CR % 16 == 0 && FM % FPC == 0, "chunk rows");
+    const int l15 = lane & 15, grp = lane >> 4;
+    const bool geglu = (g.epi & SS_EPI_GEGLU_PAIR) != 0;
+    const int M = g.M;
+    T* __restrict__ C = (T*)g.C;
+    const T* bias = (const T*)g.bias;
+    const T* res = (const T*)g.residual;
+    constexpr int RS = TN * 2 + 16;                    // strip row stride (bytes): +16 breaks the power-of-two stride
+    // per-lane bias of its 4 columns per fragment column block
+    float bv[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        bv[i][0] = bv[i][1] = bv[i][2] = bv[i][3] = 0.f;
+        if (g.epi & SS_EPI_BIAS) ld4<T>(bias + n_base + i * 16 + grp * 4, bv[i]);
+    }
+#pragma unroll
+    for (int c = 0; c < FM / FPC; ++c) {
+        // ---- stage CR rows: lane (l15, grp) holds rows j*16 + l15, columns i*16 + grp*4 .. +3 ----
+#pragma unroll
+        for (int jj = 0; jj < FPC; ++jj) {
+            const int j = c * FPC + jj;
+            const int m = m_base + j * 16 + l15;
+            float rv[FN][4];
+            if (g.rowvec) {
+                const int mm = m < M ? m : M - 1;
+                const T* rp = (const T*)g.rowvec + (int64_t)(mm / g.rows_per_batch) * g.rowvec_ld + n_base + grp * 4;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) ld4<T>(rp + i * 16, rv[i]);
+            }
+            char* rowp = stg + (jj * 16 + l15) * RS;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + bv[i][r];
+                    if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
+                    v[r] = Tr<T>::rnd(t);
+                    if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[i][r]);
+                }
+                if (geglu) {
+                    const float o0 = v[0] * Tr<T>::rnd(gelu_for<T>(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_for<T>(v[3]));
+                    float pk[8] = {o0, o1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<uint32_t*>(rowp + (i * 8 + grp * 2) * 2) = pack<T>(pk).x;
+                } else {
+                    float pk[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
+                    const uint4 u = pack<T>(pk);
+                    *reinterpret_cast<uint2*>(rowp + (i * 16 + grp * 4) * 2) = make_uint2(u.x, u.y);
+                }
+            }
+        }
+        // ---- read back whole rows (16 B per lane) and store; GEGLU rows are TN/2 outputs wide ----
+        auto readback = [&](auto lpr_tag) {
+            constexpr int LPR = decltype(lpr_tag)::value;   // lanes (16-byte pieces) per output row of the strip
+            const int n_out0 = geglu ? (n_base >> 1) : n_base;
+#pragma unroll
+            for (int k = 0; k < (CR * LPR + 63) / 64; ++k) {
+                const int idx = lane + k * 64;
+                const int row = idx / LPR, c16 = idx - row * LPR;
+                const int m = m_base + c * CR + row;
+                if (idx < CR * LPR && m < M) {
+                    uint4 u = *reinterpret_cast<const uint4*>(stg + row * RS + c16 * 16);
+                    if (g.epi & SS_EPI_RESIDUAL) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(res + (int64_t)m * g.ldr + n_base + c16 * 8);
+                        float a[8], b[8];
+                        unpack<T>(u, a);
+                        unpack<T>(rr, b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] += b[e];
+                        u = pack<T>(a);
+                    }
+                    *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n_out0 + c16 * 8) = u;
+                }
+            }
+        };
+        if (geglu) readback(std::integral_constant<int, TN / 16>{});
+        else readback(std::integral_constant<int, TN / 8>{});
     }
 }
 
