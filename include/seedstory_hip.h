@@ -148,8 +148,9 @@ int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t
  * closed-form rule — they never time, allocate or synchronise, so they stay asynchronous and hipGraph-capturable.
  * Entries come from the two explicit tuning calls below or from ss_tune_import.
  *
- * ss_gemm_tune / ss_conv3x3_tune: time every candidate tile x tile order for one shape on `stream` with HIP events
- * (cold caches: a flush fill between runs), operands synthesised (pseudo-random) inside the caller's `workspace`
+ * ss_gemm_tune / ss_conv3x3_tune: time every candidate tile x tile order for one shape on `stream` with HIP events in
+ * SUSTAINED mode (back-to-back launches over rotating weight copies that cycle through more than the Infinity Cache;
+ * the way the kernel runs inside a forward), operands synthesised (pseudo-random) inside the caller's `workspace`
  * (>= *_tune_workspace_bytes), SYNCHRONISES, stores the winner in the table; *best_us_host (optional) receives its
  * time.  `epilogue` may carry SS_EPI_GELU / SS_EPI_GEGLU_PAIR (their arithmetic is timed; bias/residual are not).
  * ss_tune_lookup: out = {cfg, xcd_group} of the entry (returns 1 and out[0] = -1 when the shape has none).

@@ -205,7 +205,7 @@ def test_gemm_every_tile_config(ops, cfg):
     assert rel(y, a.float() @ w.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69])
+@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
 @pytest.mark.parametrize("M,N,K", [(200, 300, 512), (1024, 640, 1280), (333, 1000, 64), (4096, 256, 2560), (130, 72, 192)])
 def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
     """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-23 software-pipelined) on ragged and
@@ -253,7 +253,7 @@ def test_gemm_ring_depth_k_tile_edge_cases(ops, cfg, K):
         assert torch.equal(y, ys[0])
 
 
-@pytest.mark.parametrize("cfg", [33, 35, 36, 38, 39, 40, 43, 60, 64])
+@pytest.mark.parametrize("cfg", [33, 35, 36, 38, 39, 40, 43, 60, 64, 72])
 @pytest.mark.parametrize("M,N,K", [(8200, 3840, 192), (8192, 10240, 128), (8192, 5120, 64), (16384, 2560, 640)])
 def test_gemm_persistent_multi_tile(ops, cfg, M, N, K):
     """Persistent configurations with several output tiles per workgroup (grid capped at the CU count): the next tile's

@@ -60,7 +60,7 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
-@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69])
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
 def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
@@ -91,7 +91,7 @@ def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):
         assert torch.equal(other, y)
 
 
-@pytest.mark.parametrize("cfg", [33, 36, 38, 39, 40, 43, 60, 64])
+@pytest.mark.parametrize("cfg", [33, 36, 38, 39, 40, 43, 60, 64, 72])
 def test_conv3x3_persistent_multi_tile(cfg):
     """Implicit-GEMM conv through the persistent configurations with > 1 output tile per workgroup."""
     from seedstory import _lib, ops
