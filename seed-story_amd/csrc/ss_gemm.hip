@@ -462,11 +462,12 @@ __global__ void tune_fill_kernel(uint16_t* p, size_t n, uint32_t seed, int is_bf
     }
 }
 
-// rotating weight copies of the sustained-mode tuner: up to 64 copies / 288 MB, never fewer than 2
+// rotating weight copies of the sustained-mode tuner: enough to cycle through MORE than the 256 MB Infinity Cache
+// (up to 128 copies / 352 MB), never fewer than 2
 static size_t tune_rot_bytes(size_t w_bytes) {
     const size_t wb = (w_bytes + 255) / 256 * 256;
-    size_t n = ((size_t)288 << 20) / wb;
-    if (n > 64) n = 64;
+    size_t n = ((size_t)352 << 20) / wb;
+    if (n > 128) n = 128;
     if (n < 2) n = 2;
     return n * wb;
 }
@@ -488,7 +489,7 @@ static int tune_shape(GemmArgs g, void* ws, size_t ws_bytes, size_t a_elems, hip
         const size_t a_b = up(a_elems * e), w_b = up((size_t)g.N * g.K * e), c_b = up((size_t)g.M * g.N * e);
         SS_REQUIRE(ws && ws_bytes >= a_b + 2 * w_b + c_b, "tune: workspace too small (%zu bytes)", ws_bytes);
         int nW = (int)((ws_bytes - a_b - c_b) / w_b);
-        if (nW > 64) nW = 64;
+        if (nW > 128) nW = 128;
         char* p = (char*)ws;
         g.A = p; g.C = p + a_b;
         char* w0 = p + a_b + c_b;
@@ -507,7 +508,7 @@ static int tune_shape(GemmArgs g, void* ws, size_t ws_bytes, size_t a_elems, hip
         int best = -1, best_swz = 0;
         float best_ms = 1e30f;
         const bool log = tuning_get("gemm_autotune_log", 0) != 0;
-        const int R = nW * 2 > 12 ? nW * 2 : 12;
+        const int R = nW + nW / 2 > 12 ? nW + nW / 2 : 12;
         for (int c : kTuneCands) {
             for (int z : swzs) {
                 g.swz = z;
