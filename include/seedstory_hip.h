@@ -56,6 +56,30 @@ int ss_device_info(int32_t out[4]);
 int ss_set_tuning(const char* key, int value);
 int ss_get_tuning(const char* key, int dflt);
 
+/* Device context ("no hidden global state except a per-device handle").  A process drives one GPU; the
+ * library's only state besides the thread-local error string — the tuning knobs and the GEMM tile table — belongs to
+ * that device.  ss_create validates `device` (gfx950 only), makes it the current HIP device and returns the handle that
+ * owns this state; ss_destroy drops the tile table.  Op entry points act on the current HIP device and take no handle.
+ * ss_context_info: out = {device ordinal, CU count, HBM bytes}. */
+typedef struct ss_context ss_context;
+int ss_create(int device, ss_context** out);
+int ss_context_info(const ss_context* ctx, int64_t out[3]);
+void ss_destroy(ss_context* ctx);
+
+/* RCCL exchange step of the multi-GPU slot ring (reference: single device, gen_george.py:18; the dependency between
+ * story steps is `image_embeds = torch.cat((image_embeds, image_embeds_gen))`, :224): the regressed image feature and
+ * the KV-cache rows a round appended travel from the round's owner to the other ranks (seedstory/parallel.py does the
+ * same through torch.distributed).  librccl is resolved with dlopen at the first call (SS_ESTATE when it is absent).
+ * ss_rccl_unique_id: rank 0 fills a 128-byte id and hands it to the other ranks out of band; ss_rccl_init is collective.
+ * send / recv / bcast enqueue on `stream`; `count` elements of `dtype`; bcast is in place. */
+typedef struct ss_rccl ss_rccl;
+int ss_rccl_unique_id(void* id_out_128_bytes);
+int ss_rccl_init(const void* id_128_bytes, int nranks, int rank, ss_rccl** out);
+void ss_rccl_destroy(ss_rccl* c);
+int ss_rccl_send(ss_rccl* c, const void* buf, int64_t count, int dtype, int peer, void* stream);
+int ss_rccl_recv(ss_rccl* c, void* buf, int64_t count, int dtype, int peer, void* stream);
+int ss_rccl_bcast(ss_rccl* c, void* buf, int64_t count, int dtype, int root, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Norms and element-wise ops
  * ------------------------------------------------------------------------------------- */

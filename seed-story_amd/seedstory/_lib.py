@@ -57,6 +57,15 @@ PROTOTYPES = {
     "ss_last_error": (C.c_char_p, []),
     "ss_abi_version": (C.c_int, []),
     "ss_device_info": (C.c_int, [i32p]),
+    "ss_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "ss_context_info": (C.c_int, [vp, C.POINTER(i64)]),
+    "ss_destroy": (None, [vp]),
+    "ss_rccl_unique_id": (C.c_int, [vp]),
+    "ss_rccl_init": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ss_rccl_destroy": (None, [vp]),
+    "ss_rccl_send": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "ss_rccl_recv": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "ss_rccl_bcast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
     "ss_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ss_get_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ss_rmsnorm": (C.c_int, [vp, vp, vp, i64, i64, f32, C.c_int, vp]),

@@ -340,3 +340,76 @@ def test_vis_george_sink_driver_synthetic_tiny(tmp_path):
     sinks = [int(l.rsplit("sink:", 1)[1]) for l in lines]
     assert sinks[:2] == [0, 0] and sinks[2] == 28 and sinks[3] == 52 and sinks[4] == 76     # 4 + 24 per evicted image
     assert len(list((tmp_path / "val_0").glob("ori_*.jpg"))) == 5
+
+
+def test_generate_past_key_values_kv_cache_head_numeric(golden):
+    """``LlamaForCausalLM.generate(past_key_values=…)`` with ``use_kv_cache_head`` / ``kv_cache_head``
+    (reference modeling_llama_xformer.py:676-678 attributes, :804-826 ``prepare_inputs_for_generation``: rows
+    ``[kv_cache_head:]`` of the new ``input_ids`` are fed against the cached prefix, ``position_ids`` =
+    ``cumsum(mask)-1`` sliced the same way).
+
+    (1) cached continuation of a second round == the oracle's from-scratch greedy run over the whole sequence
+        (ids exactly; hidden rows, the regressed positions and the final cache within fp32 tolerance);
+    (2) continuation from a SLICED cache (the multimodal attention sink: keys keep the RoPE phase they were cached
+        with, new rows are numbered from the trimmed length) == the oracle's ``llama_forward`` on that same past."""
+    from src.models_clm.generation import AutoImageTokenGenerationProcessor
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    g, meta = golden
+    d = meta["LLAMA"]
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    cfg = LlamaConfig(hidden_size=d["hidden"], intermediate_size=d["inter"], num_hidden_layers=d["n_layers"],
+                      num_attention_heads=d["n_heads"], vocab_size=d["vocab"])
+    llm = LlamaForCausalLM(cfg)
+    llm.load_state_dict(wd, strict=False)
+    llm = llm.to(DEV)
+    llm.cache_cap, llm.max_new, llm.max_prefill_rows = 256, 64, 64
+    img_ids = _img_ids(meta)
+    proc = [AutoImageTokenGenerationProcessor(tokenizer=_Tok(img_ids))]
+    emb = wd["model.embed_tokens.weight"]
+
+    ids1 = synth.randint(41, (1, 23), 3, img_ids[0] - 1)
+    forced1 = synth.randint(42, (6,), 3, img_ids[0] - 1).tolist()
+    llm.use_kv_cache_head, llm.kv_cache_head, llm.past_key_values = True, None, None
+    out1 = llm.generate(input_ids=ids1, inputs_embeds=emb[ids1].to(DEV), logits_processor=proc, max_new_tokens=6,
+                        forced_tokens=forced1)
+    assert out1.sequences[0, 23:].tolist() == forced1
+    assert llm.kv_cache_head == 23 + 5 and llm.past_key_values[0][0].shape[2] == 28      # the last token is not cached
+
+    # round 2: previous sequence + 9 new prompt tokens; 4 forced then 5 free-running greedy tokens
+    extra = synth.randint(43, (1, 9), 3, img_ids[0] - 1)
+    ids2 = torch.cat([out1.sequences.cpu(), extra], dim=1)
+    forced2 = synth.randint(44, (4,), 3, img_ids[0] - 1).tolist()
+    S2 = ids2.shape[1]
+    out2 = llm.generate(input_ids=ids2, inputs_embeds=emb[ids2].to(DEV), logits_processor=proc, max_new_tokens=9,
+                        past_key_values=llm.past_key_values, forced_tokens=forced2)
+    gen_o, hid_o, _, kv_o = O.greedy_generate(wd, dims, ids2, emb[ids2], img_ids, 9, forced=forced2)
+    assert out2.sequences[0, S2:].tolist() == gen_o
+    assert out2.hidden_states[0][0].shape == (1, S2 - 28, d["hidden"])                    # only rows [kv_cache_head:] were fed
+    hid_h = torch.cat([h[0].reshape(1, -1) for h in out2.hidden_states[1:]])
+    assert rel(hid_h, hid_o) < 1e-4
+    n_kv = S2 + len(gen_o) - 1
+    assert llm.kv_cache_head == n_kv and llm.past_key_values[0][0].shape[2] == n_kv
+    for l in range(d["n_layers"]):
+        assert rel(llm.past_key_values[l][0], kv_o[l][0]) < 1e-4
+        assert rel(llm.past_key_values[l][1], kv_o[l][1]) < 1e-4
+
+    # (2) sliced cache: drop cached rows [5, 17) (an evicted image span), continue with 7 new rows
+    keep = torch.cat([torch.arange(0, 5), torch.arange(17, n_kv)])
+    past_sl_o = [(k[:, :, keep].clone(), v[:, :, keep].clone()) for (k, v) in kv_o]
+    past_sl = tuple((k[:, :, keep.to(DEV)].clone(), v[:, :, keep.to(DEV)].clone()) for (k, v) in llm.past_key_values)
+    head = keep.numel()
+    seq_all = torch.cat([ids2[0], torch.tensor(gen_o)])
+    ids3 = torch.cat([seq_all[keep], seq_all[n_kv:n_kv + 1], synth.randint(45, (6,), 3, img_ids[0] - 1)]).unsqueeze(0)
+    S3 = ids3.shape[1]
+    llm.kv_cache_head = head
+    forced3 = synth.randint(46, (3,), 3, img_ids[0] - 1).tolist()
+    out3 = llm.generate(input_ids=ids3, inputs_embeds=emb[ids3].to(DEV), logits_processor=proc, max_new_tokens=3,
+                        past_key_values=past_sl, forced_tokens=forced3)
+    pos = torch.arange(head, S3).unsqueeze(0)
+    _, last_o, kv3 = O.llama_forward(wd, dims, emb[ids3[:, head:]], pos, past_sl_o)
+    assert rel(out3.hidden_states[0][0][0], last_o[0]) < 1e-4
+    x = emb[torch.tensor([[forced3[0]]])]
+    _, last_o2, kv3 = O.llama_forward(wd, dims, x, torch.tensor([[S3]]), kv3)
+    assert rel(out3.hidden_states[1][0].reshape(-1), last_o2[0, -1]) < 1e-4
+    assert llm.kv_cache_head == S3 + 2

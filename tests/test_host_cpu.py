@@ -33,6 +33,17 @@ def test_no_cpu_fallback_loud_failure():
         ops.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-5)
 
 
+def test_context_and_rccl_entry_points_fail_loudly_without_gpu():
+    """ss_create validates the device; without a GPU it reports an error instead of handing out a handle."""
+    from seedstory import _lib, comm
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SSError):
+        comm.Context(0)
+    with pytest.raises(_lib.SSError):      # NULL communicator / buffer are argument errors, not crashes
+        _lib.check(_lib.lib().ss_rccl_bcast(None, None, 0, _lib.SS_BF16, 0, None), "ss_rccl_bcast")
+
+
 def test_product_never_imports_oracle():
     bad = []
     for dp, _, fns in os.walk(PKG):
