@@ -246,8 +246,8 @@ class UNet2DConditionModel(nn.Module):
         for fn in sorted(os.listdir(folder)):
             if fn.endswith(".safetensors") and "fp16" not in fn or fn == "diffusion_pytorch_model.fp16.safetensors" and not sd:
                 sd.update(load_file(os.path.join(folder, fn)))
-        missing, unexpected = m.load_state_dict(sd, strict=False)
-        print("unet: missing keys:", len(missing), "unexpected keys:", len(unexpected))
+        from . import ckpt as _ckpt
+        _ckpt.load_checked(m, sd, "unet:")
         return m.to(torch_dtype) if torch_dtype is not None else m
 
     def init_synthetic(self, seed=0):
@@ -459,8 +459,8 @@ class AutoencoderKL(nn.Module):
         # older checkpoints name the mid-block attention projections query/key/value/proj_attn
         ren = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
         sd = {_rename(k, ren): v for k, v in sd.items()}
-        missing, unexpected = m.load_state_dict(sd, strict=False)
-        print("vae: missing keys:", len(missing), "unexpected keys (encoder etc.):", len(unexpected))
+        from . import ckpt as _ckpt
+        _ckpt.load_checked(m, sd, "vae:", expect_unexpected=("encoder.", "quant_conv."))      # decode-only module
         return m.to(torch_dtype) if torch_dtype is not None else m
 
     def init_synthetic(self, seed=0):

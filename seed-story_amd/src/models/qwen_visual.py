@@ -272,8 +272,7 @@ class VisionTransformerWithAttnPool(nn.Module):
     def from_pretrained(cls, pretrained_model_path=None, **kwargs):
         model = cls(**kwargs)
         if pretrained_model_path is not None:
-            ckpt = torch.load(pretrained_model_path, map_location="cpu")
-            missing, unexpected = model.load_state_dict(ckpt, strict=False)
+            from seedstory import ckpt as _ckpt
             print("Load ckpt of qwen visual encoder")
-            print("missing keys: ", len(missing), "unexpected keys:", len(unexpected))
+            _ckpt.load_checked(model, _ckpt.read_weights(pretrained_model_path), "qwen visual,")
         return model

@@ -140,17 +140,10 @@ class LlamaForCausalLM(nn.Module):
         """Loads an HF LLaMA folder (config.json + *.safetensors / pytorch_model*.bin)."""
         cfg = LlamaConfig.from_pretrained(pretrained_model_name_or_path)
         model = cls(cfg)
-        sd = {}
-        folder = pretrained_model_name_or_path
-        for fn in sorted(os.listdir(folder)):
-            full = os.path.join(folder, fn)
-            if fn.endswith(".safetensors"):
-                from safetensors.torch import load_file
-                sd.update(load_file(full))
-            elif fn.startswith("pytorch_model") and fn.endswith(".bin"):
-                sd.update(torch.load(full, map_location="cpu"))
-        missing, unexpected = model.load_state_dict(sd, strict=False)
-        print("llama: missing keys:", len(missing), "unexpected keys:", len(unexpected))
+        from seedstory import ckpt as _ckpt
+        sd = _ckpt.read_weights(pretrained_model_name_or_path)
+        # HF checkpoints carry the RoPE inverse-frequency buffers of older transformers versions; they are derived data
+        _ckpt.load_checked(model, {k: v for k, v in sd.items() if not k.endswith("rotary_emb.inv_freq")}, "llama:")
         if torch_dtype is not None:
             model = model.to(torch_dtype)
         return model

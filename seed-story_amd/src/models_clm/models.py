@@ -102,7 +102,6 @@ class ContinuousLVLM(nn.Module):
     def from_pretrained(cls, llm, input_resampler, output_resampler, pretrained_model_path=None, **kwargs):
         model = cls(llm=llm, input_resampler=input_resampler, output_resampler=output_resampler, **kwargs)
         if pretrained_model_path is not None:
-            ckpt = torch.load(pretrained_model_path, map_location='cpu')
-            missing, unexpected = model.load_state_dict(ckpt, strict=False)
-            print('agent model, missing keys: ', len(missing), 'unexpected keys:', len(unexpected))
+            from seedstory import ckpt as _ckpt
+            _ckpt.load_checked(model, _ckpt.read_weights(pretrained_model_path), 'agent model,')
         return model

@@ -15,6 +15,8 @@ q,k,v,o,gate,up,down; dropout inert in eval.  On the MI355X path the factors are
 weights once, in fp32 on the device, when the engine is (re)built — decode streams 13.2 GB of
 weights per token, the 14 extra rank-16 GEMVs per layer of the unmerged form are pure overhead.
 """
+import copy
+
 import torch
 from torch import nn
 
@@ -35,9 +37,7 @@ class _ModulesToSave(nn.Module):
     def __init__(self, original):
         super().__init__()
         self.original_module = original
-        copy = type(original)(original.weight.shape[0])
-        copy.weight = nn.Parameter(original.weight.data.clone(), requires_grad=False)
-        self.modules_to_save = nn.ModuleDict({"default": copy})
+        self.modules_to_save = nn.ModuleDict({"default": copy.deepcopy(original)})     # peft: deepcopy of the module
 
     @property
     def weight(self):
@@ -109,9 +109,33 @@ def get_peft_model_with_resize_embedding(model, peft_config=None, model_id=None,
         print(f"Length of tokenizer and resize embedding: {vocab_size}")
         model.resize_token_embeddings(vocab_size)
     if peft_config is None:
-        raise NotImplementedError("loading a saved adapter folder (PeftModel.from_pretrained) is not supported")
+        return PeftModel.from_pretrained(model=model, model_id=model_id)
     cfg = {k: v for k, v in dict(peft_config).items() if not k.startswith("_")}
     return PeftModelForCausalLM(model, cfg)
+
+
+class PeftModel:
+    """``PeftModel.from_pretrained(model, model_id)`` of peft==0.4.0 for a LOCAL adapter folder (reference
+    peft_models.py:63): adapter_config.json gives r / lora_alpha / target_modules / modules_to_save, adapter_model.bin the
+    factors with the adapter name stripped from the keys."""
+
+    @staticmethod
+    def from_pretrained(model, model_id, adapter_name="default", **kwargs):
+        from seedstory import ckpt as _ckpt
+        cfg, sd = _ckpt.read_peft_adapter(model_id)
+        if cfg.get("peft_type", "LORA") != "LORA":
+            raise ValueError("only LoRA adapters are on this path, got %r" % cfg.get("peft_type"))
+        pm = PeftModelForCausalLM(model, cfg)
+        missing, unexpected = pm.load_state_dict(sd, strict=False)
+        # an adapter file holds ONLY adapter tensors: base weights are "missing" by construction
+        missing = [k for k in missing if "lora_" in k or "modules_to_save" in k]
+        print("peft adapter, missing keys: ", len(missing), "unexpected keys:", len(unexpected))
+        pm.load_report = {"missing": missing, "unexpected": list(unexpected)}
+        if missing or unexpected:
+            raise KeyError("adapter %s does not match the model: missing %s unexpected %s"
+                           % (model_id, missing[:4], list(unexpected)[:4]))
+        model._engine = None
+        return pm
 
 
 def get_model_with_resize_embedding(model, vocab_size=None, torch_dtype="bf16"):

@@ -45,9 +45,8 @@ class SDXLAdapter(nn.Module):
     def from_pretrained(cls, unet, resampler, pretrained_model_path=None, **kwargs):
         model = cls(unet=unet, resampler=resampler, **kwargs)
         if pretrained_model_path is not None:
-            ckpt = torch.load(pretrained_model_path, map_location='cpu')
-            missing, unexpected = model.load_state_dict(ckpt, strict=False)
-            print('missing keys: ', len(missing), 'unexpected keys:', len(unexpected))
+            from seedstory import ckpt as _ckpt
+            _ckpt.load_checked(model, _ckpt.read_weights(pretrained_model_path), 'detokenizer,')
         return model
 
     def init_pipe(self, vae, scheduler, visual_encoder, image_transform, discrete_model=None, dtype=torch.float16,
