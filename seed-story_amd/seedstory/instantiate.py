@@ -28,7 +28,12 @@ def _wrap(node):
     return node
 
 
+# third-party targets of the reference YAMLs that this package provides itself (see the modules' headers for why)
+_ALIASES = {"transformers.LlamaTokenizer.from_pretrained": "seedstory.tokenizer.LlamaTokenizer.from_pretrained"}
+
+
 def locate(path):
+    path = _ALIASES.get(path, path)
     parts = path.split(".")
     for i in range(len(parts), 0, -1):
         try:

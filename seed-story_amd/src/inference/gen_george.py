@@ -14,11 +14,12 @@ import argparse
 import json
 import os
 import re
+import zlib
 
 import torch
 
 from seedstory import instantiate as I
-from seedstory.story import StoryContext
+from seedstory.story import PromptStory, StoryContext
 
 BOI_TOKEN = '<img>'
 EOI_TOKEN = '</img>'
@@ -27,24 +28,31 @@ CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 
 class SyntheticTokenizer:
-    """Stand-in used with --synthetic: ids 3..31999 are 'text', 32000..32065 the 66 image tokens."""
+    """Stand-in used with --synthetic: ids 3..vocab-67 are 'text' (one id per whitespace-separated word: ``w<id>`` maps
+    to ``id``, any other word to a CRC of its bytes), the last 66 ids are ``<img>``, ``<img_00000>``.., ``</img>``."""
     bos_token_id, eos_token_id = 1, 2
 
     def __init__(self, vocab=32066):
         self.vocab = vocab
         self.img = list(range(vocab - 66, vocab))
+        names = [BOI_TOKEN] + [IMG_TOKEN.format(i) for i in range(64)] + [EOI_TOKEN]
+        self.added = dict(zip(names, self.img))
+        self.names = {i: n for n, i in self.added.items()}
 
     def encode(self, s, add_special_tokens=False):
-        if s == BOI_TOKEN:
-            return [self.img[0]]
-        if s == EOI_TOKEN:
-            return [self.img[-1]]
-        if s.startswith(BOI_TOKEN):
-            return list(self.img)
-        return [3 + (hash(w) % (self.vocab - 70)) for w in s.split()]
+        ids = [self.bos_token_id] if add_special_tokens else []
+        for part in re.split(r'(</?img(?:_\d{5})?>)', s):
+            if part in self.added:
+                ids.append(self.added[part])
+                continue
+            for w in part.split():
+                m = re.fullmatch(r'w(\d+)', w)
+                ids.append(int(m.group(1)) if m and 3 <= int(m.group(1)) < self.vocab - 66
+                           else 3 + zlib.crc32(w.encode()) % (self.vocab - 70))
+        return ids
 
     def decode(self, ids, skip_special_tokens=False):
-        return " ".join("<%d>" % int(i) if int(i) >= self.vocab - 66 else "w%d" % int(i) for i in ids)
+        return " ".join(self.names[int(i)] if int(i) in self.names else "w%d" % int(i) for i in ids)
 
 
 def build(args, device, dtype):
@@ -118,10 +126,15 @@ def run_story(args, j, question, image, tokenizer, transform, vit, agent, adapte
     boi = tokenizer.encode(BOI_TOKEN, add_special_tokens=False)[0]
     eoi = tokenizer.encode(EOI_TOKEN, add_special_tokens=False)[0]
     img_all = tokenizer.encode(BOI_TOKEN + ''.join(IMG_TOKEN.format(i) for i in range(64)) + EOI_TOKEN, add_special_tokens=False)
-    ctx = StoryContext(tokenizer.bos_token_id, boi, eoi, img_all[1:-1], window=args.window)
     image_tensor = transform(image).unsqueeze(0).to(device, dtype=dtype)
-    with torch.no_grad():
-        ctx.start(tokenizer.encode(question, add_special_tokens=False), vit(image_tensor))   # gen_george.py:168-188
+    if args.parity:      # the reference's string-level prompt surgery, byte for byte (re-tokenise + '[INST]' skip)
+        ctx = PromptStory(tokenizer, window=args.window)
+        with torch.no_grad():
+            ctx.start(question, vit(image_tensor))
+    else:                # id-level context: generated ids kept verbatim
+        ctx = StoryContext(tokenizer.bos_token_id, boi, eoi, img_all[1:-1], window=args.window)
+        with torch.no_grad():
+            ctx.start(tokenizer.encode(question, add_special_tokens=False), vit(image_tensor))   # gen_george.py:168-188
     llama = agent.llm.base_model.model if hasattr(agent.llm, "base_model") else agent.llm
     llama.use_kv_cache_head = False                                                         # :165
     size = args.image_size
@@ -144,11 +157,7 @@ def run_story(args, j, question, image, tokenizer, transform, vit, agent, adapte
         images = adapter.generate(image_embeds=out['img_gen_feat'], num_inference_steps=args.diffusion_steps,
                                   height=size, width=size, input_image_size=transform.size)
         images[0].save(os.path.join(save_folder, 'ori_{:02d}.jpg'.format(step)))
-        gen = out['generate_ids'].tolist()
-        cap = gen[:gen.index(boi)] if boi in gen else gen
-        ctx.append_step(cap, out['img_gen_feat'])                                           # :224, :231
-        if ctx.over_window():
-            ctx.evict_recompute()                                                           # :235-239
+        ctx.advance(out)                                                                    # :224, :231, :235-239
     return save_folder
 
 
@@ -167,6 +176,9 @@ def main():
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--caption-tokens", type=int, default=48)
     ap.add_argument("--stories", type=int, default=1)
+    ap.add_argument("--parity", action="store_true",
+                    help="string-level prompt bookkeeping exactly as the reference driver (decode -> scrub -> re-tokenise, "
+                         "'[INST]'-length skip on eviction) instead of the id-level context")
     args = ap.parse_args()
     device = "cuda:0"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16

@@ -307,15 +307,18 @@ def test_attention_sink_continuation_matches_oracle(golden):
     assert rel(hid, ref_hid[0]) < 1e-4
 
 
-def test_gen_george_driver_synthetic_tiny(tmp_path):
+@pytest.mark.parametrize("parity", [False, True])
+def test_gen_george_driver_synthetic_tiny(tmp_path, parity):
     """The story driver end to end (ViT -> agent.generate -> adapter.generate -> JPEG, window eviction) on
-    tiny random-weight models: 4 steps with a 2-image window (forces two recompute evictions)."""
+    tiny random-weight models: 4 steps with a 2-image window (forces two recompute evictions); ``--parity`` = the
+    reference's string-level prompt bookkeeping (decode -> scrub -> re-tokenise, '[INST]' skip) instead of ids."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=os.path.join(root, "seed-story_amd"))
     out = subprocess.run([sys.executable, "-m", "src.inference.gen_george", "--synthetic", "--tiny", "--steps", "4",
                           "--window", "2", "--diffusion-steps", "2", "--image-size", "64", "--caption-tokens", "5",
-                          "--out", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600,
+                          "--out", str(tmp_path)] + (["--parity"] if parity else []),
+                         env=env, capture_output=True, text=True, timeout=600,
                          cwd=os.path.join(root, "seed-story_amd"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     folder = tmp_path / "val_0"
