@@ -407,6 +407,26 @@ int ss_euler_scale_dup(const void* x, void* xin, int64_t n, float sigma, int dty
  * EulerDiscreteScheduler.step, epsilon prediction). eps = [uncond; cond], n elements each. */
 int ss_euler_cfg_step(void* x, const void* eps, int64_t n, float guidance, float sigma, float sigma_next,
                       int dtype, void* stream);
+/* Image pre-processing on the device: the reference's `image_transform(image).to(device, dtype)`
+ * (src/processer/transforms.py:4-19 = torchvision Resize [+ CenterCrop] on a PIL image, ToTensor, Normalize;
+ * gen_george.py:166).  The resize is Pillow's 8-bit separable resampler restated bit-exactly: 22-bit fixed-point
+ * taps, horizontal pass into a uint8 intermediate, vertical pass, then fp32 (u8/255 - mean)/std rounded to `dtype`.
+ *   ss_resample_ksize / ss_resample_coeffs  HOST functions: the tap table of one axis (Pillow's precompute + normalize
+ *       coefficient steps, in double): coef [out_size * ksize] int32, bounds [out_size * 2] = {first tap, tap count}.
+ *   ss_image_preprocess  src uint8 HWC [H, W, 3] (device) -> dst [3, CH, CW] `dtype` = rows crop_top.., columns
+ *       crop_left.. of the [OH, OW] resize (CenterCrop; pass 0, 0, OH, OW for none); dst_u8_hwc (optional, [CH, CW, 3])
+ *       receives the resized uint8 pixels (what PIL would return).  coef / bounds tables are DEVICE pointers.
+ *       Only source rows [first_row, first_row + n_rows) are read (the span the cropped output needs: from
+ *       bounds_v[2*crop_top] to the last tap of row crop_top+CH-1); tmp_u8 holds n_rows * OW * 3 bytes. */
+#define SS_FILTER_BILINEAR 0 /* torchvision's default for Resize ('clip' / 'clipa' transforms) */
+#define SS_FILTER_BICUBIC 1  /* the 'sd' transform */
+int ss_resample_ksize(int64_t in_size, int64_t out_size, int filter);
+int ss_resample_coeffs(int64_t in_size, int64_t out_size, int filter, int32_t* coef, int32_t* bounds);
+int ss_image_preprocess(const void* src_u8_hwc, int64_t H, int64_t W, void* dst_chw, void* dst_u8_hwc, int64_t OH, int64_t OW,
+                        int64_t crop_top, int64_t crop_left, int64_t CH, int64_t CW, const int32_t* coef_h,
+                        const int32_t* bounds_h, int ksize_h, const int32_t* coef_v, const int32_t* bounds_v, int ksize_v,
+                        int64_t first_row, int64_t n_rows, void* tmp_u8, const float mean[3], const float std[3], int dtype,
+                        void* stream);
 /* VAE output NHWC [pixels, cpad] -> uint8 HWC: round(clamp(x/2 + 0.5, 0, 1) * 255). */
 int ss_image_to_u8(const void* in, void* out_u8, int64_t pixels, int64_t cpad, int dtype, void* stream);
 

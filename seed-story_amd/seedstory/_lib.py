@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEDSTORY_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libseedstory_hip.so"))
 
 SS_F32, SS_BF16, SS_F16 = 0, 1, 2
+SS_FILTER_BILINEAR, SS_FILTER_BICUBIC = 0, 1
 EPI_NONE, EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_GEGLU_PAIR = 0, 1, 2, 4, 8, 16
 
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -120,6 +121,10 @@ PROTOTYPES = {
     "ss_layout_nchw_nhwc": (C.c_int, [vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, vp]),
     "ss_euler_scale_dup": (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
     "ss_euler_cfg_step": (C.c_int, [vp, vp, i64, f32, f32, f32, C.c_int, vp]),
+    "ss_resample_ksize": (C.c_int, [i64, i64, C.c_int]),
+    "ss_resample_coeffs": (C.c_int, [i64, i64, C.c_int, i32p, i32p]),
+    "ss_image_preprocess": (C.c_int, [vp, i64, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, C.c_int, vp, vp, C.c_int,
+                                      i64, i64, vp, C.POINTER(f32), C.POINTER(f32), C.c_int, vp]),
     "ss_image_to_u8": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),
     "ss_debug_tr_probe": (C.c_int, [vp, vp, vp, vp]),
 }

@@ -99,6 +99,8 @@ def main():
     device = "cuda:0"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     tokenizer, transform, vit, agent, adapter = build(args, device, dtype)
+    if hasattr(transform, "to"):
+        transform.to(device, dtype)          # resize + CLIP-normalise as HIP kernels (PIL-exact), output already in HBM
     from PIL import Image
     if args.synthetic:
         words = lambda k, n: " ".join("w%d_%d" % (k, i) for i in range(n))  # noqa: E731

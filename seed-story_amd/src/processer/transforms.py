@@ -2,8 +2,13 @@
 
 ``get_transform(type, keep_ratio, image_size)`` (reference :4-47) returns a callable
 PIL.Image -> float tensor [3, S, S]: resize (bilinear for 'clip'/'clipa' — torchvision's default —
-bicubic for 'sd'), optional centre crop, scale to [0,1], normalise.  Host-side pre-processing
-(one 448x448 image per story); not a GPU hot spot.
+bicubic for 'sd'), optional centre crop, scale to [0,1], normalise.
+
+Two modes, same numbers (tests/test_preprocess.py):
+* as constructed — host PIL + torch, fp32 CPU tensor out, exactly what the reference's Compose returns;
+* after ``transform.to(device, dtype)`` — the raw uint8 pixels are uploaded and resize / crop / normalise / cast run as
+  HIP kernels (seedstory.preprocess.DevicePreprocessor; Pillow's integer resampler restated bit-exactly), the result is
+  already on the device in the model dtype so the driver's ``.to(device, dtype)`` (gen_george.py:166) is a no-op.
 """
 import numpy as np
 import torch
@@ -25,18 +30,25 @@ class _Transform:
         mean, std = _NORMS[kind]
         self.mean = torch.tensor(mean).view(3, 1, 1)
         self.std = torch.tensor(std).view(3, 1, 1)
+        self._dev = None
+
+    def to(self, device, dtype=torch.bfloat16):
+        from seedstory.preprocess import DevicePreprocessor
+        mean, std = _NORMS[self.kind]
+        self._dev = DevicePreprocessor(mean, std, self.size, keep_ratio=self.keep_ratio,
+                                       filt="bicubic" if self.kind == "sd" else "bilinear", device=device, dtype=dtype)
+        return self
 
     def __call__(self, img):
+        if self._dev is not None:
+            return self._dev(img)
         img = img.convert("RGB")
         S = self.size
         if self.keep_ratio:
+            from seedstory.preprocess import torchvision_resize_geometry
             w, h = img.size
-            if w <= h:
-                nw, nh = S, max(S, int(round(h * S / w)))
-            else:
-                nw, nh = max(S, int(round(w * S / h))), S
+            nw, nh, left, top = torchvision_resize_geometry(w, h, S, True)
             img = img.resize((nw, nh), self.resample)
-            left, top = (nw - S) // 2, (nh - S) // 2
             img = img.crop((left, top, left + S, top + S))
         else:
             img = img.resize((S, S), self.resample)
