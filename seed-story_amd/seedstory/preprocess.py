@@ -59,7 +59,7 @@ class DevicePreprocessor:
     def __call__(self, img, return_u8=False):
         """img: PIL image (converted to RGB) or uint8 tensor/array [H, W, 3].  Returns [3, S, S] on the device."""
         if hasattr(img, "convert"):
-            img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+            img = np.array(img.convert("RGB"), dtype=np.uint8)
         src = torch.as_tensor(img)
         if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
             raise _lib.SSError("expected a uint8 [H, W, 3] image")

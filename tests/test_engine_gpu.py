@@ -324,7 +324,10 @@ def test_gen_george_driver_synthetic_tiny(tmp_path, parity):
     folder = tmp_path / "val_0"
     assert sorted(p.name for p in folder.glob("ori_*.jpg")) == ["ori_01.jpg", "ori_02.jpg", "ori_03.jpg", "ori_04.jpg"]
     lens = [int(l.split(",")[1].strip(" )\n")) for l in open(folder / "token.txt")]
-    assert lens[0] == 1 + 6 + 66 and lens[1] == lens[0] + 5 + 66 and lens[3] <= lens[1] + 5 + 66   # 6-word question; window holds
+    # id level: the 5-token caption in front of the generated <img> is kept.  --parity: like the reference, the whole
+    # decoded text minus the <...> tokens is appended (random weights never emit EOS: 500 generated - 66 image tokens)
+    cap = 500 - 66 if parity else 5
+    assert lens[0] == 1 + 6 + 66 and lens[1] == lens[0] + cap + 66 and lens[3] <= lens[1] + cap + 66   # window holds
 
 
 def test_vis_george_sink_driver_synthetic_tiny(tmp_path):

@@ -462,7 +462,7 @@ def test_vae_decode_full_size_pixel_parity():
     # pin the fp32 HIP decode to the CPU oracle on a tile: decode a 32x32 latent crop with both (fully convolutional
     # except the mid attention and GroupNorm statistics, so the crop is its own complete problem)
     wd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
-    crop = lat[:, :, :32, :32].contiguous()
+    crop = lat[:, :, :32, :32].contiguous().to(torch.bfloat16).float()     # the latents both sides see (bf16 hand-over)
     ref = S.vae_decode(wd, S.SDXL_BASE_VAE, crop)
     _lib.set_tuning("vae_fp32", 1)
     try:
