@@ -407,6 +407,9 @@ def main():
                     help="N > 1: 'replicas' = independent stories per rank (throughput mode, no data-path collective); "
                          "'slots' = ONE story stream per node: rank 0 runs the MLLM recurrence, image slot t is rendered "
                          "on rank 1 + t mod (N-1) (RCCL send of img_gen_feat), BASELINE configs[3]")
+    ap.add_argument("--unet-fp8", action="store_true",
+                    help="BASELINE configs[4]: run the UNet's transformer-block linear layers through the fp8 (OCP e4m3) "
+                         "MFMA GEMM (row-wise dynamic activation scales); the headline number is the bf16 default")
     ap.add_argument("--save-tune-table", default=None, help="write the GEMM tile table of this run to this JSON path")
     args = ap.parse_args()
 
@@ -444,6 +447,8 @@ def main():
     eng, shared = build_engine(device, dtype, SPG)
     rin, rout, vit = build_frontend(device, dtype)
     adapter = None if args.mllm_only else build_detokenizer(device, dtype, vit)
+    if adapter is not None and args.unet_fp8:
+        adapter.unet.enable_fp8(True)
     runner = Runner(eng, rin, rout, vit, adapter, SPG, device, args, rank * 100003)
 
     # Tile-table entries (seedstory/tune.py) must exist before the timed region whatever --warmup is: the prompt grows
@@ -572,6 +577,42 @@ def main():
         torch.cuda.synchronize()
         gemm_us = g0.elapsed_time(g1) / 12 * 1e3
         gemm_tf = 2.0 * Mg * Ng * Kg / (gemm_us * 1e-6) / 1e12
+        # the same forward / the same GEMM with fp8 (e4m3) operands (SURVEY §8 ★ row; priced against the 5 PFLOP/s
+        # dense fp8 peak).  Not part of `value` unless --unet-fp8 was given.
+        fp8_leg = None
+        try:
+            was = getattr(adapter.unet, "_fp8", False)
+            adapter.unet.enable_fp8(True)
+            adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for _ in range(3):
+                adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
+            f1.record()
+            torch.cuda.synchronize()
+            ms8 = f0.elapsed_time(f1) / 3
+            adapter.unet.enable_fp8(was)
+            a8, sa8 = _ops.quantize_rows_fp8(ag)
+            w8s = [_ops.quantize_rows_fp8(wi) for wi in wg]
+            for i in range(2):
+                _ops.gemm_fp8(a8, sa8, w8s[i][0], w8s[i][1], bias=bg, geglu=True)
+            f0.record()
+            for i in range(12):
+                _ops.gemm_fp8(a8, sa8, w8s[i % 4][0], w8s[i % 4][1], bias=bg, geglu=True)
+            f1.record()
+            torch.cuda.synchronize()
+            us8 = f0.elapsed_time(f1) / 12 * 1e3
+            tf8 = 2.0 * Mg * Ng * Kg / (us8 * 1e-6) / 1e12
+            fp8_leg = {"forward_ms": round(ms8, 3), "speedup_vs_bf16_forward": round(ms / ms8, 3),
+                       "linear_layers": "proj_in, q|k|v, to_out, to_q, ff1 (GEGLU), ff2, proj_out of every transformer block; "
+                                        "convs / attention / context K,V stay bf16",
+                       "dominant_kernel": {"kernel": "ss::gemm_sp_kernel<fp8_t,...> (v_mfma_scale_f32_16x16x128_f8f6f4) + GEGLU epilogue",
+                                           "shape_MNK": [Mg, Ng, Kg], "avg_launch_us": round(us8, 1), "achieved": round(tf8, 1),
+                                           "unit": "TFLOP/s", "peak": 5000.0, "frac": round(tf8 / 5000.0, 4)},
+                       "in_value": bool(args.unet_fp8)}
+            del a8, sa8, w8s
+        except Exception as exc:           # the bf16 numbers above stand on their own
+            fp8_leg = {"error": str(exc)[:200]}
         del ag, wg
         roof_mllm = roof
         from seedstory import tune as _tune
@@ -587,6 +628,7 @@ def main():
                                     "achieved": round(gemm_tf, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / 2500.0, 4),
                                     "algorithmic_bytes": 2 * (Mg * Kg + Ng * Kg + Mg * Ng // 2), "traffic": ff1_traffic},
                 "note": "a round is 30 UNet forwards of batch %d (MFMA-bound) + 115 decode tokens for %d slots (HBM-bound): see mllm_decode_gemv" % (UB, SPG),
+                "unet_fp8": fp8_leg,
                 "mllm_decode_gemv": roof_mllm}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -612,7 +654,7 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True,
                "story_steps_per_step": SPG, "mllm_render_overlap": bool(overlap),
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": workload, "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
+               "config": {"workload": workload, "unet_linear_dtype": "fp8_e4m3" if args.unet_fp8 else "bf16", "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
                           "stories_per_gpu": SPG,
                           "step_definition": "one lock-step round of the %d resident stories = %d story-steps" % (SPG, SPG),

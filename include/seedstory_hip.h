@@ -56,6 +56,21 @@ int ss_device_info(int32_t out[4]);
 int ss_set_tuning(const char* key, int value);
 int ss_get_tuning(const char* key, int dflt);
 
+/* fp8 (OCP e4m3fn) GEMM path of the SDXL UNet's linear layers (SURVEY §8 ★ row; BASELINE configs[4]).  The reference
+ * has no fp8 path; this is the bf16 GEMM  C = A · W^T (+bias)(+GELU | GEGLU)(+residual)  with both operands quantised:
+ *   q = RNE_e4m3(x * 448 / amax(row)),  scale = amax(row) / 448   (activations: per token row; weights: per output channel)
+ * and  C = round_bf16(acc_fp32 * scale_a[m] * scale_w[n] + bias ...).  The matrix instruction is
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 MFMA rate on gfx950).
+ *   ss_quantize_rows_fp8  x [M, K] (16-bit dtype, row stride ld) -> q [M, K] bytes + scale [M] fp32.  With ln_gamma /
+ *       ln_beta != NULL the rows are LayerNorm-ed first (eps = ln_eps; the normalised value is rounded to `dtype` as the
+ *       unfused ss_layernorm would) — the bf16 normalised tensor is never written.  Also used once per weight at load.
+ *   ss_gemm_fp8  A8 [M, K], W8 [N, K] row-major bytes, K % 128 == 0; C / bias / residual are bf16.  Epilogue flags as
+ *       ss_gemm (BIAS, GELU, RESIDUAL, GEGLU_PAIR).  Exact w.r.t. its quantised operands (fp32 accumulation). */
+int ss_quantize_rows_fp8(const void* x, int64_t ld, int64_t M, int64_t K, void* q_out, float* scale_out, const void* ln_gamma,
+                         const void* ln_beta, float ln_eps, int dtype, void* stream);
+int ss_gemm_fp8(const void* A8, const float* scale_a, const void* W8, const float* scale_w, void* C, int64_t M, int64_t N,
+                int64_t K, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, void* stream);
+
 /* Device context ("no hidden global state except a per-device handle").  A process drives one GPU; the
  * library's only state besides the thread-local error string — the tuning knobs and the GEMM tile table — belongs to
  * that device.  ss_create validates `device` (gfx950 only), makes it the current HIP device and returns the handle that

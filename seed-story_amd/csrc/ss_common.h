@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 struct bf16_t { uint16_t v; };
 struct f16_t { uint16_t v; };
+struct fp8_t { uint8_t v; };   // OCP e4m3fn (gfx950's FP8; NOT MI300X's fnuz): GEMM operand type only, never an output
 
 // ---- scalar conversions ---------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }

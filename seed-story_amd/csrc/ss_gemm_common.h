@@ -16,9 +16,17 @@
 namespace ss {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
+// One lane's MFMA operand: NV 16-byte pieces (1 for the 16-bit 16x16x32 forms, 2 for the 128-deep fp8 form)
+template <int NV> struct Frag { uint4 v[NV]; };
+// the type results are written in (fp8 is an operand format only: activations stay bf16 between kernels)
+template <typename T> struct OutT { using type = T; };
+template <> struct OutT<fp8_t> { using type = bf16_t; };
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     static constexpr int kK = 32;
+    static constexpr int kEB = 2;   // bytes per element
+    static constexpr int kNV = 1;
     static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -29,9 +37,13 @@ template <> struct Mma<bf16_t> {
                      : "+v"(c)
                      : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
     }
+    static __device__ __forceinline__ uint32_t make_aux() { return 0u; }
+    static __device__ __forceinline__ void run_inplace(const Frag<1>& a, const Frag<1>& b, f32x4_t& c, uint32_t) { run_inplace(a.v[0], b.v[0], c); }
 };
 template <> struct Mma<f16_t> {
     static constexpr int kK = 32;
+    static constexpr int kEB = 2;
+    static constexpr int kNV = 1;
     static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                       __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -40,6 +52,35 @@ template <> struct Mma<f16_t> {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
                      : "+v"(c)
                      : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
+    }
+    static __device__ __forceinline__ uint32_t make_aux() { return 0u; }
+    static __device__ __forceinline__ void run_inplace(const Frag<1>& a, const Frag<1>& b, f32x4_t& c, uint32_t) { run_inplace(a.v[0], b.v[0], c); }
+};
+
+// OCP e4m3 x e4m3 -> fp32 through the block-scaled 128-deep instruction (the only fp8 MFMA that runs at twice the bf16
+// rate on gfx950; the 16x16x32 fp8 form runs at the bf16 rate).  Lane l supplies 32 consecutive k (bytes) of row l & 15
+// for k-block l >> 4; the hardware block scales (one E8M0 per lane = per 32 k) are held at 2^0 — tensors are scaled per
+// row / per output channel in fp32 in the epilogue instead, which keeps the quantisation grid independent of K.
+template <> struct Mma<fp8_t> {
+    static constexpr int kK = 128;
+    static constexpr int kEB = 1;
+    static constexpr int kNV = 2;
+    // The block-scale operand (E8M0 1.0 = 127 in byte 0, op_sel 0) must sit in a VGPR written LONG before the MFMA:
+    // handed to the asm as a plain constant, the compiler re-materialises it (v_mov) right in front of an asm MFMA,
+    // which is opaque to the hazard recognizer — the instruction then reads the scale register before the v_mov has
+    // landed and multiplies by whatever 2^x the register held (seen as a rare, run-dependent corruption of whole tiles).
+    // make_aux() produces it through an asm the compiler cannot look into, once per kernel.
+    static __device__ __forceinline__ uint32_t make_aux() {
+        uint32_t one;
+        asm volatile("v_mov_b32 %0, 0x7f\n\ts_nop 4" : "=v"(one));
+        return one;
+    }
+    static __device__ __forceinline__ void run_inplace(const Frag<2>& a, const Frag<2>& b, f32x4_t& c, uint32_t one) {
+        u32x8_t av = {a.v[0].x, a.v[0].y, a.v[0].z, a.v[0].w, a.v[1].x, a.v[1].y, a.v[1].z, a.v[1].w};
+        u32x8_t bv = {b.v[0].x, b.v[0].y, b.v[0].z, b.v[0].w, b.v[1].x, b.v[1].y, b.v[1].z, b.v[1].w};
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                     : "+v"(c)
+                     : "v"(av), "v"(bv), "v"(one));
     }
 };
 
@@ -73,6 +114,8 @@ struct GemmArgs {
     // implicit-GEMM 3x3 convolution over an NHWC tensor (A = [B, H, W, Cin]); K = 9 * Cin
     int conv_H, conv_W, conv_Cin, conv_stride, conv_up, conv_Ho, conv_Wo;
     int swz;   // XCD-aware tile order (0 = row-major block ids)
+    // fp8 operands: fp32 de-quantisation scales, one per A row (token) and one per W row (output channel)
+    const float* scale_a = nullptr; const float* scale_w = nullptr;
 };
 
 // Linear workgroup id -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and
@@ -159,7 +202,7 @@ __device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
     }
 }
 
-template <typename T, int FM, int FN>
+template <typename T, int FM, int FN, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                               int l15, int grp) {
     const int M = g.M, N = g.N;
@@ -176,6 +219,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         const bool full = n0 + 3 < N;
         const bool fast = full && vec_ok;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        float sw[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (SCALED) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < N) sw[r] = g.scale_w[n0 + r];
+        }
         if (g.epi & SS_EPI_BIAS) {
             if (fast) ld4<T>(bias + n0, bv);
             else {
@@ -189,6 +237,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             if (m >= M) continue;
             float v[4];
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            float sa = 1.f;
+            if constexpr (SCALED) sa = g.scale_a[m];
             if (g.rowvec) {
                 const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
                 if (fast) ld4<T>(rp + n0, rv);
@@ -199,7 +249,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = acc[i][j][r] + bv[r];
+                float t = acc[i][j][r];
+                if constexpr (SCALED) t *= sa * sw[r];
+                t += bv[r];
                 if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
                 v[r] = Tr<T>::rnd(t);
                 if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[r]);   // h = conv(x) + temb[:, :, None, None]
@@ -250,7 +302,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 // before staging (value rounded to T exactly where the direct path rounds it), the residual is added on the coalesced
 // read-back.  Requirements (checked by the caller): the wave's TM x TN sub-tile lies inside [M, N) in N (rows are
 // masked), C / residual 16-byte aligned with ldc / ldr % 8 == 0.
-template <typename T, int FM, int FN, int CR>
+template <typename T, int FM, int FN, int CR, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                      int lane, char* stg) {
     static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
@@ -266,10 +318,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
     constexpr int RS = TN * 2 + 16;                    // strip row stride (bytes): +16 breaks the power-of-two stride
     // per-lane bias of its 4 columns per fragment column block
     float bv[FN][4];
+    float swv[SCALED ? FN : 1][4];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         bv[i][0] = bv[i][1] = bv[i][2] = bv[i][3] = 0.f;
         if (g.epi & SS_EPI_BIAS) ld4<T>(bias + n_base + i * 16 + grp * 4, bv[i]);
+        if constexpr (SCALED) ld4<float>(g.scale_w + n_base + i * 16 + grp * 4, swv[i]);
     }
 #pragma unroll
     for (int c = 0; c < FM / FPC; ++c) {
@@ -286,12 +340,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                 for (int i = 0; i < FN; ++i) ld4<T>(rp + i * 16, rv[i]);
             }
             char* rowp = stg + (jj * 16 + l15) * RS;
+            float sa = 1.f;
+            if constexpr (SCALED) sa = g.scale_a[m < M ? m : M - 1];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[i][r];
+                    float t = acc[i][j][r];
+                    if constexpr (SCALED) t *= sa * swv[i][r];
+                    t += bv[i][r];
                     if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
                     v[r] = Tr<T>::rnd(t);
                     if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[i][r]);
@@ -340,5 +398,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
 // Returns SS_OK, or 1 when `cfg` is not a pipelined configuration / the shape is not eligible (the caller
 // then falls back to the double-buffered kernel).
 template <typename T> int gemm_sp_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
+// fp8 (e4m3) operands, bf16 results: ss_gemm_sp_fp8.hip
+int gemm_sp_dispatch_fp8(int cfg, const GemmArgs& g, hipStream_t s);
 
 }  // namespace ss

@@ -295,6 +295,10 @@ class UNet2DConditionModel(nn.Module):
             for n in names:
                 P["temb_all.offsets"][n] = off
                 off += sd[n + ".time_emb_proj.weight"].shape[0]
+        if getattr(self, "_fp8", False):
+            if sd[next(iter(sd))].dtype != torch.bfloat16:
+                raise _lib.SSError("the fp8 UNet path produces bf16 activations: move the module to bf16 first")
+            self._prepare_fp8(P)
         self._prep, self._prep_sig = P, sig
         self._prep_gen = getattr(self, "_prep_gen", 0) + 1      # identity of the prepared weights (graph cache key)
         return P
@@ -315,18 +319,46 @@ class UNet2DConditionModel(nn.Module):
         h, _, _ = ops.conv3x3(h, P[n + ".conv2.weight"], B, H, W, bias=P[n + ".conv2.bias"], residual=sc)
         return h
 
+    # -- fp8 (OCP e4m3) linear layers of the transformer blocks (BASELINE configs[4]; SURVEY §8 ★ row) -----------
+    def enable_fp8(self, on=True):
+        """Run proj_in / q|k|v / to_out / to_q / ff1 (GEGLU) / ff2 / proj_out of every transformer block through the fp8
+        MFMA GEMM (row-wise dynamic activation scales, per-output-channel weight scales, fp32 accumulate, bf16 out).
+        Convolutions, attention and the 64-token context K/V projection stay bf16."""
+        if bool(on) != getattr(self, "_fp8", False):
+            self._fp8 = bool(on)
+            self._prep = None          # weights are re-prepared (and a captured forward is invalidated via _prep_gen)
+        return self
+
+    def _prepare_fp8(self, P):
+        for k in list(P.keys()):
+            v = P[k]
+            if not (isinstance(v, torch.Tensor) and v.dim() == 2 and ".attentions." in k):
+                continue
+            if k.endswith(("attn1.qkv", "pairs.weight", "to_out.0.weight", "attn2.to_q.weight", "ff.net.2.weight",
+                           "proj_in.weight", "proj_out.weight")) and v.shape[1] % 128 == 0:
+                P[k + ".fp8"] = ops.quantize_rows_fp8(v.contiguous())
+
+    def _lin(self, P, name, x, *, ln=None, bias=None, residual=None, geglu=False):
+        """One linear layer of a transformer block: fp8 when enabled and prepared for this weight, else bf16."""
+        f8 = P.get(name + ".fp8") if getattr(self, "_fp8", False) else None
+        if f8 is None:
+            if ln is not None:
+                x = ops.layernorm(x, ln[0], ln[1], ln[2])
+            if geglu:
+                return ops.gemm_geglu(x, P[name], bias)
+            return ops.gemm(x, P[name], bias=bias, residual=residual)
+        x8, sx = ops.quantize_rows_fp8(x, ln=ln)
+        return ops.gemm_fp8(x8, sx, f8[0], f8[1], bias=bias, residual=residual, geglu=geglu)
+
     def _transformer(self, P, n, x, B, HW, ctx2d, Lctx, heads, layers, groups):
-        C = x.shape[1]
         h = ops.groupnorm(x, P[n + ".norm.weight"], P[n + ".norm.bias"], B, groups, 1e-6, silu=False)
-        h = ops.gemm(h, P[n + ".proj_in.weight"], bias=P[n + ".proj_in.bias"])
+        h = self._lin(P, n + ".proj_in.weight", h, bias=P[n + ".proj_in.bias"])
         for k in range(layers):
             b = n + ".transformer_blocks.%d" % k
-            y = ops.layernorm(h, P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5)
-            qkv = ops.gemm(y, P[b + ".attn1.qkv"])
+            qkv = self._lin(P, b + ".attn1.qkv", h, ln=(P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5))
             a = ops.attention_qkv_packed(qkv, B, HW, heads)
-            h = ops.gemm(a, P[b + ".attn1.to_out.0.weight"], bias=P[b + ".attn1.to_out.0.bias"], residual=h)
-            y = ops.layernorm(h, P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5)
-            q = ops.gemm(y, P[b + ".attn2.to_q.weight"])
+            h = self._lin(P, b + ".attn1.to_out.0.weight", a, bias=P[b + ".attn1.to_out.0.bias"], residual=h)
+            q = self._lin(P, b + ".attn2.to_q.weight", h, ln=(P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5))
             kv = self._ctx_kv.get(b)
             if kv is None:   # K/V of the 64 context tokens do not depend on the denoising step: once per image,
                 # written into a per-block buffer that keeps its address (a captured forward reads it on replay)
@@ -339,11 +371,11 @@ class UNet2DConditionModel(nn.Module):
                     self._kv_gen = getattr(self, "_kv_gen", 0) + 1      # a captured forward holding the old address is stale
                 kv = self._ctx_kv[b] = ops.gemm(ctx2d, w, out=buf)
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
-            h = ops.gemm(a, P[b + ".attn2.to_out.0.weight"], bias=P[b + ".attn2.to_out.0.bias"], residual=h)
-            y = ops.layernorm(h, P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5)
-            u = ops.gemm_geglu(y, P[b + ".ff.net.0.proj.pairs.weight"], P[b + ".ff.net.0.proj.pairs.bias"])
-            h = ops.gemm(u, P[b + ".ff.net.2.weight"], bias=P[b + ".ff.net.2.bias"], residual=h)
-        return ops.gemm(h, P[n + ".proj_out.weight"], bias=P[n + ".proj_out.bias"], residual=x)
+            h = self._lin(P, b + ".attn2.to_out.0.weight", a, bias=P[b + ".attn2.to_out.0.bias"], residual=h)
+            u = self._lin(P, b + ".ff.net.0.proj.pairs.weight", h, ln=(P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5),
+                          bias=P[b + ".ff.net.0.proj.pairs.bias"], geglu=True)
+            h = self._lin(P, b + ".ff.net.2.weight", u, bias=P[b + ".ff.net.2.bias"], residual=h)
+        return self._lin(P, n + ".proj_out.weight", h, bias=P[n + ".proj_out.bias"], residual=x)
 
     @torch.no_grad()
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **kw):

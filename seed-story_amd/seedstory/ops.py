@@ -177,6 +177,32 @@ def gemm_geglu(a, w_pairs, bias_pairs):
     return out
 
 
+def quantize_rows_fp8(x, ln=None):
+    """x [M, K] (bf16 / fp16) -> (q uint8 [M, K] holding OCP e4m3 bytes, scale fp32 [M]); ``ln`` = (gamma, beta, eps)
+    fuses a LayerNorm in front (the normalised bf16 tensor is never written)."""
+    _req(x)
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    check(lib().ss_quantize_rows_fp8(p(x), x.stride(0), M, K, p(q), p(sc), p(g), p(b), float(eps), dt(x), stream()),
+          "ss_quantize_rows_fp8")
+    return q, sc
+
+
+def gemm_fp8(a8, sa, w8, sw, bias=None, residual=None, gelu=False, geglu=False, out=None):
+    """(a8 * sa[:, None]) @ (w8 * sw[:, None])^T (+bias)(+gelu | geglu pairs)(+residual) -> bf16 [M, N (N/2 for geglu)]."""
+    M, K = a8.shape
+    N = w8.shape[0]
+    No = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, No, dtype=torch.bfloat16, device=a8.device)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RESIDUAL if residual is not None else 0) | \
+        (_lib.EPI_GEGLU_PAIR if geglu else 0)
+    check(lib().ss_gemm_fp8(p(a8), p(sa), p(w8), p(sw), p(out), M, N, K, No, p(bias), p(residual), No, epi, stream()), "ss_gemm_fp8")
+    return out
+
+
 def gemv(w, x, norm_w=None, eps=0.0, bias=None, residual=None, silu_mul=False):
     _req(w); _req(x)
     N, K = w.shape

@@ -144,6 +144,51 @@ def cmd_unet(UB):
     json.dump(out, open(os.path.join(OUT, "unet_time_b%d.json" % UB), "w"))
 
 
+def cmd_fp8(UB):
+    """fp8 vs bf16: the UNet's linear shapes one by one (sustained: 20 back-to-back launches over rotating operands would
+    be colder; here the operands are > L2 for the large shapes) and the whole forward."""
+    import math
+    from seedstory.diffusion import UNet2DConditionModel
+    dt = torch.bfloat16
+    res = {"gemm": []}
+    T32, T64 = UB * 1024, UB * 4096
+    for (M, N, K, geglu) in [(T32, 3840, 1280, False), (T32, 1280, 1280, False), (T32, 10240, 1280, True), (T32, 1280, 5120, False),
+                             (T64, 1920, 640, False), (T64, 640, 640, False), (T64, 5120, 640, True), (T64, 640, 2560, False)]:
+        a = torch.randn(M, K, device=DEV, dtype=dt)
+        w = torch.randn(N, K, device=DEV, dtype=dt) / math.sqrt(K)
+        bias = torch.randn(N, device=DEV, dtype=dt)
+        a8, sa = ops.quantize_rows_fp8(a)
+        w8, sw = ops.quantize_rows_fp8(w)
+        row = {"M": M, "N": N, "K": K, "geglu": geglu}
+        flops = 2.0 * M * N * K
+        for cfg in (81, 82, 80):
+            _lib.set_tuning("gemm_fp8_cfg", cfg)
+            us = min(timed(lambda: ops.gemm_fp8(a8, sa, w8, sw, bias=bias, geglu=geglu), n=10) for _ in range(2))
+            row["fp8_cfg%d_us" % cfg] = round(us, 1)
+            row["fp8_cfg%d_tflops" % cfg] = round(flops / us / 1e6, 1)
+        _lib.set_tuning("gemm_fp8_cfg", 0)
+        row["fp8_us"] = round(min(timed(lambda: ops.gemm_fp8(a8, sa, w8, sw, bias=bias, geglu=geglu), n=10) for _ in range(2)), 1)
+        row["quant_us"] = round(min(timed(lambda: ops.quantize_rows_fp8(a), n=10) for _ in range(2)), 1)
+        f16 = (lambda: ops.gemm_geglu(a, w, bias)) if geglu else (lambda: ops.gemm(a, w, bias=bias))
+        row["bf16_us"] = round(min(timed(f16, n=10) for _ in range(2)), 1)
+        row["bf16_tflops"] = round(flops / row["bf16_us"] / 1e6, 1)
+        print(row)
+        res["gemm"].append(row)
+    unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
+    x = torch.randn(UB, 4, 128, 128, device=DEV, dtype=dt)
+    ctx = torch.randn(UB, 64, 2048, device=DEV, dtype=dt)
+    cond = {"text_embeds": torch.randn(UB, 1280, device=DEV, dtype=dt),
+            "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * UB, dtype=torch.float32)}
+    for mode in (False, True):
+        unet.enable_fp8(mode)
+        unet(x, 500.0, ctx, added_cond_kwargs=cond)
+        torch.cuda.synchronize()
+        us = min(timed(lambda: unet(x, 500.0, ctx, added_cond_kwargs=cond), n=3, warm=0) for _ in range(2))
+        res["unet_forward_ms_%s" % ("fp8" if mode else "bf16")] = round(us / 1e3, 2)
+    print({k: v for k, v in res.items() if k != "gemm"})
+    json.dump(res, open(os.path.join(OUT, "fp8_bench_b%d.json" % UB), "w"), indent=0)
+
+
 def cmd_vae():
     from seedstory.diffusion import AutoencoderKL
     dt = torch.bfloat16
@@ -169,3 +214,5 @@ if __name__ == "__main__":
         cmd_unet(batch)
     elif cmd == "vae":
         cmd_vae()
+    elif cmd == "fp8":
+        cmd_fp8(batch)
