@@ -397,8 +397,9 @@ int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, 
                int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
                int64_t rowvec_stride, const void* residual, int dtype, void* stream);
 
-/* nn.GroupNorm over NHWC (+ optional fused SiLU): fp32 statistics per (batch, group);
- * stats_ws = batch*groups*2 floats of scratch. */
+/* nn.GroupNorm over NHWC (+ optional fused SiLU): statistics per (batch, group) accumulated with fp64 atomics (the
+ * result does not depend on the order the partial sums land in: two runs agree); stats_ws = batch*groups*2 DOUBLES
+ * (16 * batch * groups bytes) of scratch. */
 int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch,
                  int64_t hw, int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream);
 

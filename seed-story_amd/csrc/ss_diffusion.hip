@@ -12,7 +12,8 @@ __device__ __forceinline__ float gelu_d(float v) { return 0.5f * v * (1.0f + erf
 
 // =====================================================================================
 // GroupNorm over NHWC: statistics per (batch, group) of H*W x (C/G) elements.
-//   pass 1: partial sum / sum-of-squares per block -> fp32 atomics into stats[b][g][2]
+//   pass 1: partial sum / sum-of-squares per block -> fp64 atomics into stats[b][g][2] (fp64 so that the result does not
+//           depend on the order the atomics land in: two runs of the same forward agree, as the reference's do)
 //   pass 2: y = (x - mean) * rstd * gamma[c] + beta[c]  (+ SiLU), rounded once to T
 // (torch GroupNorm computes in fp32 and rounds the result; SiLU then rounds again.)
 // =====================================================================================
@@ -27,16 +28,16 @@ __device__ __forceinline__ float silu_fast(float g) {
 // HBM rate instead of being bound by per-element integer divisions and LDS atomics.
 //   thread t of a block: pack p = pc + t % cw, first row r0 + t / cw, row stride 256 / cw   (cw = packs per chunk)
 template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ stats,
                                                               int HW, int C, int G, int rows_per_block) {
     constexpr int V = Tr<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sh = reinterpret_cast<float*>(smem_raw);  // [G][2]
+    double* sh = reinterpret_cast<double*>(smem_raw);  // [G][2]
     const int b = blockIdx.y;
     const int cg = C / G, ppr = C / V;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(HW, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.0;
     __syncthreads();
     const T* xb = x + ((int64_t)b * HW) * C;
     for (int pc = 0; pc < ppr; pc += 256) {
@@ -73,22 +74,22 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
         for (int j = 0; j < V; ++j) {
             const int gj = (p * V + j) / cg;
             if (gj != g) {
-                atomicAdd(sh + 2 * g, a1);
-                atomicAdd(sh + 2 * g + 1, a2);
+                unsafeAtomicAdd(sh + 2 * g, (double)a1);
+                unsafeAtomicAdd(sh + 2 * g + 1, (double)a2);
                 g = gj; a1 = 0.f; a2 = 0.f;
             }
             a1 += s1[j];
             a2 += s2[j];
         }
-        atomicAdd(sh + 2 * g, a1);
-        atomicAdd(sh + 2 * g + 1, a2);
+        unsafeAtomicAdd(sh + 2 * g, (double)a1);
+        unsafeAtomicAdd(sh + 2 * g + 1, (double)a2);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(stats + (int64_t)b * G * 2 + i, sh[i]);
+    for (int i = threadIdx.x; i < 2 * G; i += 256) unsafeAtomicAdd(stats + (int64_t)b * G * 2 + i, sh[i]);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, const double* __restrict__ stats,
                                                               const T* __restrict__ gamma, const T* __restrict__ beta,
                                                               T* __restrict__ y, int HW, int C, int G, float eps,
                                                               int silu, int rows_per_block) {
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int g = (p * V + j) / cg;
-            const float s1 = stats[((int64_t)b * G + g) * 2], s2 = stats[((int64_t)b * G + g) * 2 + 1];
-            const float mean = s1 * inv_n;
-            const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+            const double md = stats[((int64_t)b * G + g) * 2] * (double)inv_n;      // E[x^2] - mean^2 in fp64: no cancellation
+            const float mean = (float)md;
+            const float var = (float)fmax(stats[((int64_t)b * G + g) * 2 + 1] * (double)inv_n - md * md, 0.0);
             const float rstd = 1.0f / sqrtf(var + eps);
             sc[j] = rstd * ga[j];
             sh[j] = be[j] - mean * sc[j];
@@ -143,19 +144,19 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 }
 
 template <typename T>
-int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, float* stats, int64_t B, int64_t HW,
+int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, double* stats, int64_t B, int64_t HW,
                      int64_t C, int64_t G, float eps, int silu, hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(C % G == 0 && C % V == 0, "groupnorm: C=%lld G=%lld unsupported", (long long)C, (long long)G);
     if (B * HW == 0) return SS_OK;
-    SS_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), s));
+    SS_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s));
     // ~128 KiB of activations per block, at least enough blocks to fill the chip several times
     int rows_per_block = (int)((128 * 1024) / (C * sizeof(T)));
     if (rows_per_block < 16) rows_per_block = 16;
     while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 2048) rows_per_block /= 2;
     if (rows_per_block > HW) rows_per_block = (int)HW;
     dim3 grid((unsigned)cdiv(HW, rows_per_block), (unsigned)B);
-    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), (size_t)G * 2 * sizeof(float), s, (const T*)x, stats,
+    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), (size_t)G * 2 * sizeof(double), s, (const T*)x, stats,
                        (int)HW, (int)C, (int)G, rows_per_block);
     SS_LAUNCH_CHECK("groupnorm_stats");
     hipLaunchKernelGGL(groupnorm_apply_kernel<T>, grid, dim3(256), 0, s, (const T*)x, stats, (const T*)gamma,
@@ -401,7 +402,7 @@ extern "C" {
 
 int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch, int64_t hw,
                  int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream) {
-    return SS_DISPATCH(dtype, groupnorm_launch, x, gamma, beta, y, (float*)stats_ws, batch, hw, channels, groups, eps,
+    return SS_DISPATCH(dtype, groupnorm_launch, x, gamma, beta, y, (double*)stats_ws, batch, hw, channels, groups, eps,
                        fuse_silu, (hipStream_t)stream);
 }
 int ss_geglu(const void* in, void* out, int64_t rows, int64_t d, int dtype, void* stream) {

@@ -58,12 +58,15 @@ def per_case(tag):
         if rows and "Dispatch_Id" in rows[0]:
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         cur = None
+        last_marker = None
         seq = []
         for r in rows:
             k = norm(r["Kernel_Name"])
             if "softmax_rows" in k:
-                cur = collections.defaultdict(list)
-                seq.append(cur)
+                if r.get("Dispatch_Id") != last_marker:      # one row per counter for the same dispatch
+                    cur = collections.defaultdict(list)
+                    seq.append(cur)
+                    last_marker = r.get("Dispatch_Id")
                 continue
             if cur is None or not ("gemm_sp_kernel" in k or "flash_attn" in k or "gemm_glds" in k):
                 continue
