@@ -175,6 +175,7 @@ class LlamaForCausalLM(nn.Module):
         return flat
 
     def engine_for_generation(self, img_ids):
+        self._img_ids = tuple(img_ids)      # forward() reuses the engine of the last generate() instead of rebuilding
         lora = getattr(self, "_lora_scaling", None)
         p0 = self.lm_head.weight
         sig = (p0.data_ptr(), p0._version, p0.dtype, str(p0.device), tuple(img_ids), self.cache_cap, self.max_new,
@@ -192,6 +193,84 @@ class LlamaForCausalLM(nn.Module):
                                        eos_id=c.eos_token_id, lora_scaling=lora if lora is not None else 2.0)
             self._engine_sig = sig
         return self._engine
+
+    # ---- single forward call (reference :703-794, inference part) ------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        """One model call with the reference's argument meaning: ``inputs_embeds`` (or ``input_ids``) [1, q] rows are fed
+        after ``past_key_values`` (tuple over layers of (k, v) [1, heads, kv, head_dim], keys post-RoPE); ``position_ids``
+        [1, q] default to kv .. kv+q-1; the mask is always the bottom-right causal one (the reference passes
+        ``attention_mask=None`` down from ``prepare_inputs_for_generation``, :826,844).  Returns logits for ALL q rows
+        (lm_head on every row, :759), the grown cache, and — unlike the reference, which can return every layer's input —
+        ``hidden_states = (last,)``: the post-final-norm states, the only entry the path reads (models.py:182-197 uses
+        ``hidden_states[-1]``).  Side effects as the reference: ``self.past_key_values`` (:778), ``kv_cache_head``
+        (:780-784).  ``labels`` (training loss, :761-772) is outside the inference path."""
+        if labels is not None:
+            raise NotImplementedError("training loss (reference :761-772) is outside the inference hot path")
+        if output_attentions:
+            raise NotImplementedError("attention probabilities are never materialised (flash attention)")
+        eng = self.engine_for_generation(tuple(getattr(self, "_img_ids", ())))
+        dev = eng.device
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids.to(dev))
+        if inputs_embeds.shape[0] != 1:
+            raise ValueError("the story path is batch 1")
+        rows = inputs_embeds[0].to(dev)
+        q = rows.shape[0]
+        if past_key_values is None:
+            eng.reset()
+            kv = 0
+        else:
+            eng.load_past_key_values(past_key_values)
+            kv = eng.lengths()[0]
+        pos = None
+        if position_ids is not None:
+            pos = position_ids.reshape(-1).to(device=dev, dtype=torch.int32)
+        elif kv:
+            pos = torch.arange(kv, kv + q, dtype=torch.int32, device=dev)
+        hid = eng.prefill(rows, pos_ids=pos, want_hidden=True)                    # [q, H], post final norm
+        from seedstory import ops as _ops
+        logits = _ops.gemm(hid.contiguous(), self.lm_head.weight).unsqueeze(0)     # [1, q, V]
+        pkv = eng.past_key_values()
+        self.past_key_values = pkv
+        if self.use_kv_cache_head and not self.training:
+            n_in = q if input_ids is None else input_ids.shape[1]
+            self.kv_cache_head = n_in if self.kv_cache_head is None else self.kv_cache_head + n_in
+        out = CausalLMOutputWithPast(logits=logits, past_key_values=pkv,
+                                     hidden_states=(hid.unsqueeze(0),) if output_hidden_states else None)
+        if return_dict is False:
+            return (logits, pkv) + ((out.hidden_states,) if output_hidden_states else ())
+        return out
+
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      **kwargs):
+        """What HF's greedy loop feeds each step (reference :796-852).  With ``use_kv_cache_head`` and a cache, the rows
+        ``[kv_cache_head:]`` of the running sequence go in (ids, and embeds when more than one row is left) with the
+        matching slice of ``cumsum(mask) - 1`` as positions; otherwise the last token only.  Embeddings are used on the
+        first step only.  The mask itself is dropped (the attention is bottom-right causal by construction)."""
+        head_mode = self.use_kv_cache_head and not self.training
+        cut = self.kv_cache_head if head_mode else -1
+        if past_key_values:
+            input_ids = input_ids[:, cut:]
+            if head_mode and inputs_embeds is not None:
+                inputs_embeds = inputs_embeds[:, cut:]
+        position_ids = kwargs.get("position_ids", None)
+        if attention_mask is not None and position_ids is None:
+            position_ids = attention_mask.long().cumsum(-1) - 1
+            position_ids.masked_fill_(attention_mask == 0, 1)
+            if past_key_values:
+                position_ids = position_ids[:, cut:].unsqueeze(-1) if head_mode else position_ids[:, -1].unsqueeze(-1)
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs = {"inputs_embeds": inputs_embeds, "input_ids": input_ids}
+        elif head_mode and past_key_values is not None and input_ids.shape[1] > 1:
+            model_inputs = {"inputs_embeds": inputs_embeds, "input_ids": input_ids}
+        else:
+            model_inputs = {"input_ids": input_ids}
+        model_inputs.update({"position_ids": position_ids, "past_key_values": past_key_values,
+                             "use_cache": kwargs.get("use_cache"), "attention_mask": None})
+        return model_inputs
 
     @torch.no_grad()
     def generate(self, input_ids=None, inputs_embeds=None, logits_processor=None, past_key_values=None,
@@ -221,6 +300,9 @@ class LlamaForCausalLM(nn.Module):
             pos = torch.arange(head, S, dtype=torch.int32, device=dev)      # cumsum(mask)-1 sliced (:811-816)
             hid0 = eng.prefill(rows[head:], pos_ids=pos, want_hidden=output_hidden_states)
             eng.set_lengths(eng.lengths()[0], S)
+        if max_new_tokens > eng.max_new:
+            raise ValueError("max_new_tokens=%d exceeds the engine's generated-token ring (max_new=%d): raise "
+                             "LlamaForCausalLM.max_new before the first generate()" % (max_new_tokens, eng.max_new))
         n = eng.generate(max_new_tokens, int(input_ids[0, -1]), forced_tokens)
         gen = eng.gen_ids[:n].to(torch.long)
         sequences = torch.cat([input_ids[0], gen]).unsqueeze(0)
@@ -235,6 +317,15 @@ class LlamaForCausalLM(nn.Module):
             adv = fed0 + max(n - 1, 0)
             self.kv_cache_head = adv if self.kv_cache_head is None else self.kv_cache_head + adv
         return GenerateOutput(sequences=sequences, hidden_states=hidden_states, attentions=None)
+
+
+class CausalLMOutputWithPast:
+    def __init__(self, logits, past_key_values, hidden_states=None, loss=None, attentions=None):
+        self.loss, self.logits, self.past_key_values = loss, logits, past_key_values
+        self.hidden_states, self.attentions = hidden_states, attentions
+
+    def __getitem__(self, i):
+        return (self.logits, self.past_key_values, self.hidden_states)[i]
 
 
 class GenerateOutput:

@@ -419,3 +419,62 @@ def test_generate_past_key_values_kv_cache_head_numeric(golden):
     _, last_o2, kv3 = O.llama_forward(wd, dims, x, torch.tensor([[S3]]), kv3)
     assert rel(out3.hidden_states[1][0].reshape(-1), last_o2[0, -1]) < 1e-4
     assert llm.kv_cache_head == S3 + 2
+
+
+def test_forward_call_and_manual_greedy_loop(golden):
+    """``LlamaForCausalLM.forward`` (reference :703-794) + ``prepare_inputs_for_generation`` (:796-852) driven the way HF's
+    greedy search drives them: logits of ALL rows vs the oracle, cache growth, ``kv_cache_head``
+    bookkeeping, and a hand-rolled loop (prepare -> forward -> image-token processor -> argmax) that reproduces both
+    ``generate()`` and the oracle's greedy ids."""
+    from src.models_clm.generation import AutoImageTokenGenerationProcessor
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    g, meta = golden
+    d = meta["LLAMA"]
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    llm = LlamaForCausalLM(LlamaConfig(hidden_size=d["hidden"], intermediate_size=d["inter"], num_hidden_layers=d["n_layers"],
+                                       num_attention_heads=d["n_heads"], vocab_size=d["vocab"]))
+    llm.load_state_dict(wd, strict=False)
+    llm = llm.to(DEV).eval()
+    llm.cache_cap, llm.max_new, llm.max_prefill_rows = 256, 32, 64
+    img_ids = _img_ids(meta)
+    emb = wd["model.embed_tokens.weight"]
+    ids = synth.randint(61, (1, 21), 3, img_ids[0] - 1)
+    # (1) one call, all-row logits; then a 4-row continuation against the returned cache
+    llm.use_kv_cache_head, llm.kv_cache_head = True, None
+    out = llm(input_ids=ids.to(DEV), inputs_embeds=emb[ids].to(DEV), output_hidden_states=True)
+    lo, last_o, kv_o = O.llama_forward(wd, dims, emb[ids], torch.arange(21).unsqueeze(0), None)
+    assert out.logits.shape == (1, 21, d["vocab"]) and rel(out.logits, lo) < 1e-4
+    assert rel(out.hidden_states[-1], last_o) < 1e-4 and out.past_key_values[0][0].shape[2] == 21
+    assert llm.kv_cache_head == 21 and llm.past_key_values is out.past_key_values
+    more = synth.randint(62, (1, 4), 3, img_ids[0] - 1)
+    out2 = llm(input_ids=more.to(DEV), past_key_values=out.past_key_values, position_ids=torch.arange(21, 25).unsqueeze(0))
+    lo2, _, _ = O.llama_forward(wd, dims, emb[more], torch.arange(21, 25).unsqueeze(0), kv_o)
+    assert rel(out2.logits, lo2) < 1e-4 and llm.kv_cache_head == 25 and out2.past_key_values[1][1].shape[2] == 25
+    with pytest.raises(NotImplementedError):
+        llm(input_ids=ids.to(DEV), labels=ids.to(DEV))
+    # (2) the greedy loop by hand (use_kv_cache_head = False, gen_george.py:165)
+    llm.use_kv_cache_head, llm.kv_cache_head = False, None
+    proc = AutoImageTokenGenerationProcessor(tokenizer=_Tok(img_ids))
+    seq = ids.to(DEV)
+    mask = torch.ones_like(seq)
+    past, gen = None, []
+    for step in range(8):
+        inp = llm.prepare_inputs_for_generation(seq, past_key_values=past, attention_mask=mask,
+                                                inputs_embeds=emb[ids].to(DEV) if step == 0 else None, use_cache=True)
+        kw = {k: v for k, v in inp.items() if k in ("input_ids", "inputs_embeds", "position_ids", "past_key_values")}
+        if kw.get("inputs_embeds") is None:
+            kw.pop("inputs_embeds", None)
+        o = llm(**kw)
+        scores = proc(seq, o.logits[:, -1, :].float().contiguous())
+        tok = int(scores.argmax(-1))
+        gen.append(tok)
+        seq = torch.cat([seq, torch.tensor([[tok]], device=DEV)], dim=1)
+        mask = torch.ones_like(seq)
+        past = o.past_key_values
+    gen_o, _, _, _ = O.greedy_generate(wd, dims, ids, emb[ids], img_ids, 8)
+    assert gen == gen_o[:8]
+    g2 = llm.generate(input_ids=ids, inputs_embeds=emb[ids].to(DEV), logits_processor=[proc], max_new_tokens=8)
+    assert g2.sequences[0, 21:].tolist() == gen_o[:8]
+    with pytest.raises(ValueError):
+        llm.generate(input_ids=ids, inputs_embeds=emb[ids].to(DEV), logits_processor=[proc], max_new_tokens=33)   # > max_new

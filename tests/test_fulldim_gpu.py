@@ -530,3 +530,37 @@ def test_continuous_lvlm_generate_bf16_vs_reference_bf16(golden):
           % (ours_bf16, ours_f32, ref_gap))
     assert ours_bf16 < 2e-2
     assert ours_f32 <= 1.5 * ref_gap + 1e-3
+
+
+def test_lora_merged_bf16_drift_full_width():
+    """a7: the engine merges ``W + (alpha/r) B A`` once (fp32 accumulate, one rounding to bf16) where peft runs
+    the adapter UNMERGED in bf16 (``x W^T`` and ``(x A^T) B^T * scaling`` each rounded).  At LLaMA-7B width (2 layers, r=16,
+    alpha=32 on all seven projections): the merged engine must sit no further from the fp32 unmerged truth than the
+    reference's own bf16 unmerged run does (1.5x + 2e-3), and within bf16 noise of that bf16 run."""
+    from seedstory.llama import LlamaEngine
+    bf = torch.bfloat16
+    w32 = dict(_llama_weights())
+    gl = torch.Generator().manual_seed(77)
+    for k in [k for k in w32 if k.endswith("_proj.weight")]:
+        o, i = w32[k].shape
+        w32[k[:-len("weight")] + "lora_A.weight"] = torch.randn(16, i, generator=gl) * 0.02
+        w32[k[:-len("weight")] + "lora_B.weight"] = torch.randn(o, 16, generator=gl) * 0.02
+    wbf = {k: v.to(bf) for k, v in w32.items()}
+    dims = O.LlamaDims(H, NH, NL, INTER, VOCAB)
+    ids = synth.randint(730, (1, 115), 3, 32000)
+    pos = torch.arange(115).unsqueeze(0)
+    lg32, hid32, _ = O.llama_forward(w32, dims, w32["model.embed_tokens.weight"][ids], pos, None, 2.0, all_logits=False)
+    lgbf, hidbf, _ = O.llama_forward(wbf, dims, wbf["model.embed_tokens.weight"][ids], pos, None, 2.0, all_logits=False)
+    eng = LlamaEngine(wbf, hidden=H, n_heads=NH, n_layers=NL, inter=INTER, vocab=VOCAB, dtype=bf, device=DEV, cache_cap=256,
+                      max_new=16, max_prefill_rows=128, img_ids=IMG_IDS, lora_scaling=2.0)
+    hid = eng.prefill(wbf["model.embed_tokens.weight"][ids[0]], want_hidden=True)
+    e_bf, e_32, theirs = rel(hid, hidbf[0]), rel(hid, hid32[0]), rel(hidbf[0], hid32[0])
+    l_bf, l_32, l_theirs = rel(eng.logits, lgbf[0, -1]), rel(eng.logits, lg32[0, -1]), rel(lgbf[0, -1], lg32[0, -1])
+    print("LoRA merged (HIP bf16) vs unmerged: hidden vs ref-bf16 %.3e | vs fp32 %.3e | ref-bf16 vs fp32 %.3e ; logits %.3e | %.3e | %.3e"
+          % (e_bf, e_32, theirs, l_bf, l_32, l_theirs))
+    # the update really matters here (dropping it moves the output by far more than any rounding)
+    w_no = {k: v for k, v in w32.items() if ".lora_" not in k}
+    _, hid_no, _ = O.llama_forward(w_no, dims, w32["model.embed_tokens.weight"][ids], pos, None, 2.0, all_logits=False)
+    assert rel(hid_no[0], hid32[0]) > 5e-2
+    assert e_bf < 2e-2 and e_32 <= 1.5 * theirs + 2e-3
+    assert l_bf < 2e-2 and l_32 <= 1.5 * l_theirs + 2e-3

@@ -365,3 +365,23 @@ def test_vae_decode_dtype_policy():
         assert v.to(torch.float16).decode_dtype() == torch.float32
     finally:
         _lib.set_tuning("vae_fp32", 0)
+
+
+def test_prepare_inputs_for_generation_matches_reference_fixture():
+    """``LlamaForCausalLM.prepare_inputs_for_generation`` (reference :796-852) on every branch — kv_cache_head slicing vs
+    last-token slicing, embeds on the first step only, positions from ``cumsum(mask) - 1`` — against outputs of the REAL
+    reference function (tests/golden/prepare_inputs.json, generated by oracle/make_golden_prepare_inputs.py)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from make_golden_prepare_inputs import build_args, encode
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "prepare_inputs.json")))
+    m = LlamaForCausalLM(LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=1, vocab_size=50))
+    m.eval()
+    assert len(fx["cases"]) == 88
+    for rec in fx["cases"]:
+        c = rec["case"]
+        m.use_kv_cache_head, m.kv_cache_head = c["use_head"], c["head"]
+        ids, past, mask, emb = build_args(c)
+        out = m.prepare_inputs_for_generation(ids, past_key_values=past, attention_mask=mask, inputs_embeds=emb, use_cache=True)
+        assert encode(out) == rec["out"], c
