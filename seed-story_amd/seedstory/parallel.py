@@ -115,6 +115,17 @@ class SlotRingBackend:
         raise NotImplementedError
 
 
+def _bcast(t, src, group=None):
+    """Broadcast in place.  RCCL moves device tensors directly; under gloo (the CPU tests and the single-device flow test
+    of the N > 1 path) device tensors are staged through host memory — gloo's CUDA transport is not part of ROCm builds."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu", first_round=0):
     """Advance the stream by ``n_rounds`` rounds (round r is owned by rank (first_round + r) mod world).  Returns
     the list of rounds this rank rendered.  Collective order is identical on every rank: per round one header
@@ -140,13 +151,13 @@ def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu",
             header[0] = len(meta)
             header[1:1 + len(meta)] = torch.tensor(list(meta), dtype=torch.int64)
         if world > 1:
-            dist.broadcast(header, src=owner, group=group)
+            _bcast(header, owner, group)
         if rank != owner:
             meta = header[1:1 + int(header[0])].tolist()
             tensors = backend.alloc(meta)
         if world > 1:
             for t in tensors:
-                dist.broadcast(t, src=owner, group=group)
+                _bcast(t, owner, group)
         if rank == owner:
             rendered.append(r)
             pending.append(pool.submit(render_job, r, meta, tensors))
@@ -269,6 +280,9 @@ def bench_slot_partition(args, rank, world, device, dtype, bm):
     be = StoryRingBackend(bm, eng, rin, rout, vit, adapter, args.stories_per_gpu, device, dtype, args.diffusion_steps)
     gloo = bool(os.environ.get("SS_BENCH_SINGLE_DEVICE"))
     meta_dev = "cpu" if gloo else device
+    if os.environ.get("SS_BENCH_WATCHDOG_S"):       # flow tests: dump every thread's stack and exit instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SS_BENCH_WATCHDOG_S"]), exit=True)
     # every rank owns one MLLM round and renders once before the clock starts (tile-table entries, graph capture)
     run_slot_ring(be, max(world, args.warmup), rank, world, meta_device=meta_dev)
     be.sts = None

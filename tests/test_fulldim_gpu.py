@@ -562,5 +562,6 @@ def test_lora_merged_bf16_drift_full_width():
     w_no = {k: v for k, v in w32.items() if ".lora_" not in k}
     _, hid_no, _ = O.llama_forward(w_no, dims, w32["model.embed_tokens.weight"][ids], pos, None, 2.0, all_logits=False)
     assert rel(hid_no[0], hid32[0]) > 5e-2
-    assert e_bf < 2e-2 and e_32 <= 1.5 * theirs + 2e-3
-    assert l_bf < 2e-2 and l_32 <= 1.5 * l_theirs + 2e-3
+    # (two independent bf16 roundings of the same fp32 function sit about as far from each other as from the truth)
+    assert e_bf < 1.2 * theirs + 2e-3 and e_32 <= 1.5 * theirs + 2e-3
+    assert l_bf < 1.2 * l_theirs + 2e-3 and l_32 <= 1.5 * l_theirs + 2e-3
