@@ -5,10 +5,17 @@
     PYTHONPATH=seed-story_amd python -m src.inference.gen_george --val data/json/val.jsonl        # real checkpoints
     PYTHONPATH=seed-story_amd python -m src.inference.gen_george --synthetic --tiny --steps 4     # random weights
 
-Differences from the reference script, all behaviour-preserving: one ``main()`` instead of module-level code;
-token-id level context management (``seedstory.story.StoryContext``) instead of string surgery + full
-re-tokenisation; ``--window-mode sink`` switches the eviction policy to the multimodal attention sink on the
-KV slab (the reference's vis_george_sink.py computes it and then discards it, :316).
+Differences from the reference script:
+* structural only: one ``main()`` instead of module-level code; the image transform runs on the device
+  (``transform.to(device, dtype)``: Pillow-exact resize + normalise as HIP kernels, bit-identical tensor).
+* **intentional deviation (default mode)**: the context is managed at token-id level (``seedstory.story.StoryContext``) —
+  the generated caption ids in front of ``<img>`` are appended verbatim and eviction cuts at the first ``</img>`` id.
+  The reference appends the decoded, regex-scrubbed TEXT (everything generated minus ``<...>`` tokens, ``</s>`` included),
+  re-tokenises the whole prompt every step, and on eviction also drops ``len('[INST]')`` = 6 more characters of the next
+  caption (:196,231-243); after the first step its token stream can therefore differ from the id-level one at
+  tokenisation boundaries and by those six characters.
+* ``--parity`` reproduces the reference's string surgery byte for byte (``seedstory.story.PromptStory``) for A/B checks
+  against the reference on real checkpoints; it re-prefills everything each step like the reference does.
 """
 import argparse
 import json
