@@ -550,6 +550,8 @@ def main():
         ctx = torch.randn(UB, 64, 2048, device=device, dtype=dtype)
         cond = {"text_embeds": torch.randn(UB, 1280, device=device, dtype=dtype),
                 "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * UB, dtype=torch.float32)}
+        fp8_was = getattr(adapter.unet, "_fp8", False)
+        adapter.unet.enable_fp8(False)                         # this block prices the bf16 forward whatever --unet-fp8 says
         adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -581,7 +583,7 @@ def main():
         # dense fp8 peak).  Not part of `value` unless --unet-fp8 was given.
         fp8_leg = None
         try:
-            was = getattr(adapter.unet, "_fp8", False)
+            was = fp8_was
             adapter.unet.enable_fp8(True)
             adapter.unet(x, 500.0, ctx, added_cond_kwargs=cond)
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
