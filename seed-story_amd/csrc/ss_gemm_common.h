@@ -306,7 +306,7 @@ template <typename T, int FM, int FN, int CR, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                      int lane, char* stg) {
     static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
-    constexpr int TN = FN * 16, TMw = FM * 16;
+    constexpr int TN = FN * 16;
     constexpr int FPC = CR / 16;                       // M fragments per chunk
     static_assert(CR % 16 == 0 && FM % FPC == 0, "chunk rows");
     const int l15 = lane & 15, grp = lane >> 4;

@@ -63,7 +63,7 @@ __global__ void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, T* __res
 }
 
 template <typename T>
-int preprocess_launch(const void* src, int64_t H, int64_t W, void* dst, void* dst_u8, int64_t OH, int64_t OW, int64_t crop_top,
+int preprocess_launch(const void* src, int64_t /*H*/, int64_t W, void* dst, void* dst_u8, int64_t /*OH*/, int64_t OW, int64_t crop_top,
                       int64_t crop_left, int64_t CH, int64_t CW, const int* coef_h, const int* bounds_h, int ksize_h,
                       const int* coef_v, const int* bounds_v, int ksize_v, int y0, int rows, void* tmp, const float* mean,
                       const float* std, hipStream_t stream) {
