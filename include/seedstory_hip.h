@@ -56,6 +56,21 @@ int ss_device_info(int32_t out[4]);
 int ss_set_tuning(const char* key, int value);
 int ss_get_tuning(const char* key, int dflt);
 
+/* LayerNorm folded into the GEMM that consumes it (the UNet's norm1 -> q|k|v, norm2 -> to_q, norm3 -> ff1; reference:
+ * diffusers BasicTransformerBlock, `attn(norm(h))`): with  LN(h) = (h - mean) * rstd * gamma + beta
+ *     LN(h) · W^T + b  =  rstd[m] * (h · Wg^T)[m][n]  -  rstd[m] * mean[m] * c[n]  +  d[n]
+ * where Wg = gamma ∘ W (rounded to the model dtype once at load), c[n] = sum_k Wg[n][k] (fp32), d[n] = b[n] + sum_k
+ * beta[k] W[n][k].  The normalised activation tensor is never written or re-read: the GEMM streams the RAW rows, the
+ * epilogue applies  t = acc * rstd[m] + shift[m] * c[n] + d[n]  (shift = -mean * rstd) in fp32 and continues with GELU /
+ * GEGLU pairs as ss_gemm does.  Rounding differs from the unfused form (LN output not rounded to bf16; gamma rounded
+ * into the weight): same order of magnitude, covered by the bf16 parity gates.
+ *   ss_rowstats     x [M, K] (16-bit, row stride ld, K <= 2048) -> rstd_out[M], shift_out[M] (fp32)
+ *   ss_gemm_lnfold  A [M, K] raw rows, Wg [N, K]; `bias` carries d (model dtype); K % 64 == 0, N % 16 == 0;
+ *                   epilogue flags BIAS | GELU | GEGLU_PAIR. */
+int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream);
+int ss_gemm_lnfold(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
+                   const float* shift, const float* colsum, const void* bias, int epilogue, int dtype, void* stream);
+
 /* fp8 (OCP e4m3fn) GEMM path of the SDXL UNet's linear layers (SURVEY §8 ★ row; BASELINE configs[4]).  The reference
  * has no fp8 path; this is the bf16 GEMM  C = A · W^T (+bias)(+GELU | GEGLU)(+residual)  with both operands quantised:
  *   q = RNE_e4m3(x * 448 / amax(row)),  scale = amax(row) / 448   (activations: per token row; weights: per output channel)

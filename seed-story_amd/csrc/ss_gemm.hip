@@ -610,6 +610,92 @@ int conv_tune_launch(int64_t B, int64_t H, int64_t Wd, int64_t Cin, int64_t Cout
     return tune_shape<T>(g, ws, ws_bytes, (size_t)B * H * Wd * Cin, s, us);
 }
 
+// GEMM with a LayerNorm folded into it (see ss_gemm_lnfold in the header).  Runs the shape's own tile (table / rule)
+// in its folded-epilogue instantiation (id + 100: the staged family 60..72).
+template <typename T>
+int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
+                       const float* shift, const float* colsum, const void* bias, int epi, hipStream_t s) {
+    if constexpr (Tr<T>::kVec != 8) {
+        set_error("ss_gemm_lnfold: 16-bit dtypes only");
+        return SS_EINVAL;
+    } else {
+        SS_REQUIRE(K % 64 == 0 && N % 16 == 0, "ss_gemm_lnfold: K %% 64 and N %% 16 must be 0 (K=%lld N=%lld)", (long long)K, (long long)N);
+        SS_REQUIRE(!(epi & ~(SS_EPI_BIAS | SS_EPI_GELU | SS_EPI_GEGLU_PAIR)), "ss_gemm_lnfold: unsupported epilogue %d", epi);
+        SS_REQUIRE(!(epi & SS_EPI_BIAS) || bias, "ss_gemm_lnfold: bias epilogue without bias");
+        SS_REQUIRE(rstd && shift && colsum && (((size_t)colsum) & 15) == 0, "ss_gemm_lnfold: row / column vectors missing or misaligned");
+        if (M == 0 || N == 0) return SS_OK;
+        GemmArgs g;
+        g.A = A; g.W = Wg; g.C = C; g.bias = bias; g.residual = nullptr;
+        g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = K; g.ldw = K; g.ldc = ldc; g.ldr = 0; g.epi = epi;
+        g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
+        g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
+        g.swz = tuning_get("gemm_xcd_swizzle", 8);
+        g.scale_a = rstd; g.shift_a = shift; g.scale_w = colsum;
+        int cfg = lookup_cfg<T>(g);
+        if (cfg < 60 || cfg > 72) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : (M * N >= 128 * 128 * 256 ? 65 : 70);
+        const int rc = gemm_sp_dispatch<T>(cfg + 100, g, s);
+        if (rc == 1) {
+            set_error("ss_gemm_lnfold: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 100, (long long)M, (long long)N, (long long)K);
+            return SS_EINVAL;
+        }
+        return rc;
+    }
+}
+
+// per-row LayerNorm statistics in the form the folded epilogue consumes: rstd[m] and -mean[m] * rstd[m]; one wave per row,
+// two-pass variance on the register-resident row (the arithmetic of layernorm_wave_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols, float eps,
+                                                       float* __restrict__ rstd, float* __restrict__ shift) {
+    constexpr int V = Tr<T>::kVec;
+    constexpr int MAXP = 4;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int npack = cols / V;
+    const T* xr = x + (int64_t)row * ld;
+    uint4 px[MAXP];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = lane + i * 64;
+        if (p < npack) {
+            px[i] = *reinterpret_cast<const uint4*>(xr + (int64_t)p * V);
+            float f[V];
+            unpack<T>(px[i], f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s1 += f[j];
+        }
+    }
+    const float mean = wave_sum(s1) / (float)cols;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int p = lane + i * 64;
+        if (p < npack) {
+            float f[V];
+            unpack<T>(px[i], f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = f[j] - mean; s2 = fmaf(d, d, s2); }
+        }
+    }
+    const float r = 1.0f / sqrtf(wave_sum(s2) / (float)cols + eps);
+    if (lane == 0) { rstd[row] = r; shift[row] = -mean * r; }
+}
+
+template <typename T>
+int rowstats_launch(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd, float* shift, hipStream_t s) {
+    if constexpr (Tr<T>::kVec != 8) {
+        set_error("ss_rowstats: 16-bit dtypes only");
+        return SS_EINVAL;
+    } else {
+        SS_REQUIRE(K % 8 == 0 && K / 8 <= 256 && ld % 8 == 0, "ss_rowstats: K=%lld unsupported (multiple of 8, <= 2048)", (long long)K);
+        hipLaunchKernelGGL(rowstats_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)x, ld, (int)M, (int)K, eps, rstd, shift);
+        SS_LAUNCH_CHECK("rowstats");
+        return SS_OK;
+    }
+}
+
 int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
              int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, int dtype, hipStream_t s) {
     return SS_DISPATCH(dtype, gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epi, s);
@@ -631,6 +717,17 @@ int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t
             int64_t ldw, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue,
             int dtype, void* stream) {
     return ss::gemm_dev(A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue, dtype, (hipStream_t)stream);
+}
+
+int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream) {
+    SS_REQUIRE(x && rstd_out && shift_out && M > 0 && K > 0 && ld >= K, "ss_rowstats: bad arguments");
+    return SS_DISPATCH(dtype, ss::rowstats_launch, x, ld, M, K, eps, rstd_out, shift_out, (hipStream_t)stream);
+}
+
+int ss_gemm_lnfold(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
+                   const float* shift, const float* colsum, const void* bias, int epilogue, int dtype, void* stream) {
+    SS_REQUIRE(A && Wg && C, "ss_gemm_lnfold: NULL argument");
+    return SS_DISPATCH(dtype, ss::gemm_lnfold_launch, A, Wg, C, M, N, K, ldc, rstd, shift, colsum, bias, epilogue, (hipStream_t)stream);
 }
 
 size_t ss_gemm_tune_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {

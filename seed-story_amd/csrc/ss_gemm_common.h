@@ -116,6 +116,8 @@ struct GemmArgs {
     int swz;   // XCD-aware tile order (0 = row-major block ids)
     // fp8 operands: fp32 de-quantisation scales, one per A row (token) and one per W row (output channel)
     const float* scale_a = nullptr; const float* scale_w = nullptr;
+    // folded LayerNorm (16-bit operands): scale_a = rstd[m], shift_a = -mean[m] * rstd[m], scale_w = c[n] (see EM below)
+    const float* shift_a = nullptr;
 };
 
 // Linear workgroup id -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and
@@ -202,7 +204,10 @@ __device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
     }
 }
 
-template <typename T, int FM, int FN, bool SCALED = false>
+// EM (epilogue scaling mode): 0 none | 1 fp8 de-quantisation  t = acc * scale_a[m] * scale_w[n]  | 2 folded LayerNorm
+//   t = acc * scale_a[m] + shift_a[m] * scale_w[n]   (scale_a = rstd, shift_a = -mean * rstd, scale_w = column sums of the
+//   gamma-scaled weight; beta's contribution rides in the bias) — see ss_gemm_lnfold
+template <typename T, int FM, int FN, int EM = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                               int l15, int grp) {
     const int M = g.M, N = g.N;
@@ -220,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         const bool fast = full && vec_ok;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         float sw[4] = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (SCALED) {
+        if constexpr (EM != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n0 + r < N) sw[r] = g.scale_w[n0 + r];
         }
@@ -237,8 +242,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             if (m >= M) continue;
             float v[4];
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            float sa = 1.f;
-            if constexpr (SCALED) sa = g.scale_a[m];
+            float sa = 1.f, sh = 0.f;
+            if constexpr (EM != 0) sa = g.scale_a[m];
+            if constexpr (EM == 2) sh = g.shift_a[m];
             if (g.rowvec) {
                 const T* rp = (const T*)g.rowvec + (int64_t)(m / g.rows_per_batch) * g.rowvec_ld;
                 if (fast) ld4<T>(rp + n0, rv);
@@ -250,7 +256,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[i][j][r];
-                if constexpr (SCALED) t *= sa * sw[r];
+                if constexpr (EM == 1) t *= sa * sw[r];
+                if constexpr (EM == 2) t = fmaf(t, sa, sh * sw[r]);
                 t += bv[r];
                 if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
                 v[r] = Tr<T>::rnd(t);
@@ -302,7 +309,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 // before staging (value rounded to T exactly where the direct path rounds it), the residual is added on the coalesced
 // read-back.  Requirements (checked by the caller): the wave's TM x TN sub-tile lies inside [M, N) in N (rows are
 // masked), C / residual 16-byte aligned with ldc / ldr % 8 == 0.
-template <typename T, int FM, int FN, int CR, bool SCALED = false>
+template <typename T, int FM, int FN, int CR, int EM = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                      int lane, char* stg) {
     static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
@@ -318,12 +325,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
     constexpr int RS = TN * 2 + 16;                    // strip row stride (bytes): +16 breaks the power-of-two stride
     // per-lane bias of its 4 columns per fragment column block
     float bv[FN][4];
-    float swv[SCALED ? FN : 1][4];
+    float swv[EM != 0 ? FN : 1][4];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         bv[i][0] = bv[i][1] = bv[i][2] = bv[i][3] = 0.f;
         if (g.epi & SS_EPI_BIAS) ld4<T>(bias + n_base + i * 16 + grp * 4, bv[i]);
-        if constexpr (SCALED) ld4<float>(g.scale_w + n_base + i * 16 + grp * 4, swv[i]);
+        if constexpr (EM != 0) ld4<float>(g.scale_w + n_base + i * 16 + grp * 4, swv[i]);
     }
 #pragma unroll
     for (int c = 0; c < FM / FPC; ++c) {
@@ -340,15 +347,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                 for (int i = 0; i < FN; ++i) ld4<T>(rp + i * 16, rv[i]);
             }
             char* rowp = stg + (jj * 16 + l15) * RS;
-            float sa = 1.f;
-            if constexpr (SCALED) sa = g.scale_a[m < M ? m : M - 1];
+            float sa = 1.f, sh = 0.f;
+            if constexpr (EM != 0) sa = g.scale_a[m < M ? m : M - 1];
+            if constexpr (EM == 2) sh = g.shift_a[m < M ? m : M - 1];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = acc[i][j][r];
-                    if constexpr (SCALED) t *= sa * swv[i][r];
+                    if constexpr (EM == 1) t *= sa * swv[i][r];
+                    if constexpr (EM == 2) t = fmaf(t, sa, sh * swv[i][r]);
                     t += bv[i][r];
                     if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
                     v[r] = Tr<T>::rnd(t);

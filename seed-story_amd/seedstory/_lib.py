@@ -58,6 +58,8 @@ PROTOTYPES = {
     "ss_last_error": (C.c_char_p, []),
     "ss_abi_version": (C.c_int, []),
     "ss_device_info": (C.c_int, [i32p]),
+    "ss_rowstats": (C.c_int, [vp, i64, i64, i64, f32, vp, vp, C.c_int, vp]),
+    "ss_gemm_lnfold": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "ss_quantize_rows_fp8": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, f32, C.c_int, vp]),
     "ss_gemm_fp8": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp]),
     "ss_create": (C.c_int, [C.c_int, C.POINTER(vp)]),

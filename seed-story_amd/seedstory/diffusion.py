@@ -295,6 +295,8 @@ class UNet2DConditionModel(nn.Module):
             for n in names:
                 P["temb_all.offsets"][n] = off
                 off += sd[n + ".time_emb_proj.weight"].shape[0]
+        if getattr(self, "_lnfold", False) and sd[next(iter(sd))].dtype in (torch.bfloat16, torch.float16):
+            self._prepare_lnfold(P)
         if getattr(self, "_fp8", False):
             if sd[next(iter(sd))].dtype != torch.bfloat16:
                 raise _lib.SSError("the fp8 UNet path produces bf16 activations: move the module to bf16 first")
@@ -329,6 +331,35 @@ class UNet2DConditionModel(nn.Module):
             self._prep = None          # weights are re-prepared (and a captured forward is invalidated via _prep_gen)
         return self
 
+    def enable_lnfold(self, on=True):
+        """Fold norm1 / norm2 / norm3 of every transformer block into the GEMM that follows (q|k|v, to_q, GEGLU ff1):
+        the GEMM streams the raw rows, the epilogue applies the per-row statistics (`ss_rowstats` + `ss_gemm_lnfold`);
+        the three LayerNorm launches and their normalised tensors disappear.  bf16 path only (fp8 fuses the LayerNorm into
+        its quantiser instead)."""
+        if bool(on) != getattr(self, "_lnfold", False):
+            self._lnfold = bool(on)
+            self._prep = None
+        return self
+
+    def _prepare_lnfold(self, P):
+        """Wg = gamma ∘ W (one rounding to the model dtype), c = row sums of Wg (fp32), d = b + W · beta."""
+        for k in list(P.keys()):
+            if not k.endswith(".norm1.weight") or ".transformer_blocks." not in k:
+                continue
+            b = k[:-len(".norm1.weight")]
+            for norm, wkey, bkey in ((".norm1", ".attn1.qkv", None), (".norm2", ".attn2.to_q.weight", None),
+                                     (".norm3", ".ff.net.0.proj.pairs.weight", ".ff.net.0.proj.pairs.bias")):
+                W = P[b + wkey]
+                if W.shape[1] % 64 or W.shape[0] % 16:
+                    continue
+                gamma, beta = P[b + norm + ".weight"].float(), P[b + norm + ".bias"].float()
+                wg = (W.float() * gamma[None, :]).to(W.dtype).contiguous()
+                c = wg.float().sum(dim=1).contiguous()
+                d = W.float() @ beta
+                if bkey is not None:
+                    d = d + P[b + bkey].float()
+                P[b + wkey + ".lnf"] = (wg, c, d.to(W.dtype).contiguous())
+
     def _prepare_fp8(self, P):
         for k in list(P.keys()):
             v = P[k]
@@ -350,15 +381,23 @@ class UNet2DConditionModel(nn.Module):
         x8, sx = ops.quantize_rows_fp8(x, ln=ln)
         return ops.gemm_fp8(x8, sx, f8[0], f8[1], bias=bias, residual=residual, geglu=geglu)
 
+    def _lin_ln(self, P, name, x, ln, bias=None, geglu=False):
+        """LayerNorm + linear: folded (ss_gemm_lnfold) when enabled and prepared for this weight."""
+        lnf = P.get(name + ".lnf") if getattr(self, "_lnfold", False) and not getattr(self, "_fp8", False) else None
+        if lnf is None:
+            return self._lin(P, name, x, ln=ln, bias=bias, geglu=geglu)
+        rstd, shift = ops.rowstats(x, ln[2])
+        return ops.gemm_lnfold(x, lnf[0], rstd, shift, lnf[1], bias_d=lnf[2], geglu=geglu)
+
     def _transformer(self, P, n, x, B, HW, ctx2d, Lctx, heads, layers, groups):
         h = ops.groupnorm(x, P[n + ".norm.weight"], P[n + ".norm.bias"], B, groups, 1e-6, silu=False)
         h = self._lin(P, n + ".proj_in.weight", h, bias=P[n + ".proj_in.bias"])
         for k in range(layers):
             b = n + ".transformer_blocks.%d" % k
-            qkv = self._lin(P, b + ".attn1.qkv", h, ln=(P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5))
+            qkv = self._lin_ln(P, b + ".attn1.qkv", h, (P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5))
             a = ops.attention_qkv_packed(qkv, B, HW, heads)
             h = self._lin(P, b + ".attn1.to_out.0.weight", a, bias=P[b + ".attn1.to_out.0.bias"], residual=h)
-            q = self._lin(P, b + ".attn2.to_q.weight", h, ln=(P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5))
+            q = self._lin_ln(P, b + ".attn2.to_q.weight", h, (P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5))
             kv = self._ctx_kv.get(b)
             if kv is None:   # K/V of the 64 context tokens do not depend on the denoising step: once per image,
                 # written into a per-block buffer that keeps its address (a captured forward reads it on replay)
@@ -372,8 +411,8 @@ class UNet2DConditionModel(nn.Module):
                 kv = self._ctx_kv[b] = ops.gemm(ctx2d, w, out=buf)
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
             h = self._lin(P, b + ".attn2.to_out.0.weight", a, bias=P[b + ".attn2.to_out.0.bias"], residual=h)
-            u = self._lin(P, b + ".ff.net.0.proj.pairs.weight", h, ln=(P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5),
-                          bias=P[b + ".ff.net.0.proj.pairs.bias"], geglu=True)
+            u = self._lin_ln(P, b + ".ff.net.0.proj.pairs.weight", h, (P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5),
+                             bias=P[b + ".ff.net.0.proj.pairs.bias"], geglu=True)
             h = self._lin(P, b + ".ff.net.2.weight", u, bias=P[b + ".ff.net.2.bias"], residual=h)
         return self._lin(P, n + ".proj_out.weight", h, bias=P[n + ".proj_out.bias"], residual=x)
 

@@ -177,6 +177,29 @@ def gemm_geglu(a, w_pairs, bias_pairs):
     return out
 
 
+def rowstats(x, eps):
+    """Per-row LayerNorm statistics for `gemm_lnfold`: (rstd [M], -mean * rstd [M]) fp32."""
+    _req(x)
+    M, K = x.shape
+    st = torch.empty(2, M, dtype=torch.float32, device=x.device)
+    check(lib().ss_rowstats(p(x), x.stride(0), M, K, float(eps), p(st[0]), p(st[1]), dt(x), stream()), "ss_rowstats")
+    return st[0], st[1]
+
+
+def gemm_lnfold(x, wg, rstd, shift, colsum, bias_d=None, gelu=False, geglu=False):
+    """LN(x) @ W^T + b with the LayerNorm folded: x raw rows, wg = gamma-scaled weight, colsum = wg.sum(1) fp32, bias_d = d."""
+    _req(x); _req(wg)
+    M, K = x.shape
+    N = wg.shape[0]
+    No = N // 2 if geglu else N
+    out = torch.empty(M, No, dtype=x.dtype, device=x.device)
+    epi = (EPI_BIAS if bias_d is not None else 0) | (EPI_GELU if gelu else 0) | (_lib.EPI_GEGLU_PAIR if geglu else 0)
+    tune.ensure_gemm(M, N, K, dt(x), epi, x.device)
+    check(lib().ss_gemm_lnfold(p(x), p(wg), p(out), M, N, K, No, p(rstd), p(shift), p(colsum), p(bias_d), epi, dt(x), stream()),
+          "ss_gemm_lnfold")
+    return out
+
+
 def quantize_rows_fp8(x, ln=None):
     """x [M, K] (bf16 / fp16) -> (q uint8 [M, K] holding OCP e4m3 bytes, scale fp32 [M]); ``ln`` = (gamma, beta, eps)
     fuses a LayerNorm in front (the normalised bf16 tensor is never written)."""

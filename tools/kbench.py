@@ -131,6 +131,8 @@ def cmd_unet(UB):
     from seedstory.diffusion import UNet2DConditionModel
     dt = torch.bfloat16
     unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
+    if os.environ.get("KB_LNFOLD"):
+        unet.enable_lnfold(True)
     x = torch.randn(UB, 4, 128, 128, device=DEV, dtype=dt)
     ctx = torch.randn(UB, 64, 2048, device=DEV, dtype=dt)
     cond = {"text_embeds": torch.randn(UB, 1280, device=DEV, dtype=dt),
@@ -138,8 +140,8 @@ def cmd_unet(UB):
     unet(x, 500.0, ctx, added_cond_kwargs=cond)
     torch.cuda.synchronize()
     ops.softmax_rows_(torch.zeros(1, 8, device=DEV, dtype=dt), 1.0)   # marker kernel for tools/trace_summary.py
-    us = timed(lambda: unet(x, 500.0, ctx, added_cond_kwargs=cond), n=3, warm=0)
-    out = {"unet_batch": UB, "forward_ms_eager": round(us / 1e3, 2), "tflops": round(UB * 6.747e12 / (us * 1e-6) / 1e12, 1)}
+    us = min(timed(lambda: unet(x, 500.0, ctx, added_cond_kwargs=cond), n=3, warm=0) for _ in range(2))
+    out = {"lnfold": bool(os.environ.get("KB_LNFOLD")), "unet_batch": UB, "forward_ms_eager": round(us / 1e3, 2), "tflops": round(UB * 6.747e12 / (us * 1e-6) / 1e12, 1)}
     print(out)
     json.dump(out, open(os.path.join(OUT, "unet_time_b%d.json" % UB), "w"))
 
