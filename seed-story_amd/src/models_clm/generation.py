@@ -6,7 +6,6 @@ On the MI355X path the processor's rule (reference :19-31) is applied *on the de
 decode graph (``ss_imgproc_argmax`` / the engine's sample kernel) — no ``.item()`` host sync per
 token; calling the object on tensors runs the same device kernel for API compatibility.
 """
-import torch
 
 from seedstory import ops
 

@@ -10,7 +10,6 @@ import csv
 import glob
 import json
 import os
-import re
 import sys
 
 R = os.path.join("gpurun_out", "r2")
