@@ -147,13 +147,25 @@ def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
             eng.reset()
             eng.prefill(emb)
     forced = [st.forced() for st in sts]
-    if len(sts) == 1:
-        ns = [eng.generate(500, sts[0].ids[-1], forced[0])]               # max_new_tokens=500 (gen_george.py:194)
-    else:
-        ns = eng.generate_batch(500, [st.ids[-1] for st in sts], forced)  # the same loop, all slots per weight sweep
-    assert all(n == T_GEN for n in ns), ns
     e = CAPTION + 65                                                      # index of </img> in the generated ids
-    feats = torch.stack([eng.select(b).hidden_rows[e - 64:e] for b in range(len(sts))]).contiguous()   # models.py:197
+    if eng.img_block_enabled():
+        # the decode loop stops at <img>; the 65 tokens the logits processor forces behind it are fed as ONE batched
+        # continuation per story (same layers / attention / hidden rows / KV entries, weights streamed once), then the
+        # loop resumes (seedstory/llama.py: generate_img_block).  T_GEN tokens per story either way.
+        if len(sts) == 1:
+            g1, h1 = eng.generate_img_block(T_GEN, sts[0].ids[-1], forced[0])
+            gens, hids = [g1], [h1]
+        else:
+            gens, hids = eng.generate_batch_img_block(T_GEN, [st.ids[-1] for st in sts], forced)
+        assert all(len(g) == T_GEN and g[e] == IMG_IDS[-1] for g in gens), [len(g) for g in gens]
+        feats = torch.stack([h[e - 64:e] for h in hids]).contiguous()
+    else:
+        if len(sts) == 1:
+            ns = [eng.generate(500, sts[0].ids[-1], forced[0])]               # max_new_tokens=500 (gen_george.py:194)
+        else:
+            ns = eng.generate_batch(500, [st.ids[-1] for st in sts], forced)  # the same loop, all slots per weight sweep
+        assert all(n == T_GEN for n in ns), ns
+        feats = torch.stack([eng.select(b).hidden_rows[e - 64:e] for b in range(len(sts))]).contiguous()   # models.py:197
     img_gen_feat = rout(feats)                                            # models.py:205  [S,256,4096]
     for b, st in enumerate(sts):
         advance_context(st, forced[b], img_gen_feat[b:b + 1])
@@ -658,6 +670,11 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload, "unet_linear_dtype": "fp8_e4m3" if args.unet_fp8 else "bf16", "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
+                          "img_block_decode": bool(eng.img_block_enabled()),
+                          "img_block_decode_note": "the 65 tokens the logits processor forces behind <img> are fed as ONE batched "
+                                                   "continuation per story (same layers / attention / hidden rows / KV entries / "
+                                                   "per-position lm_head as the token-by-token loop, weights streamed once); "
+                                                   "SEEDSTORY_IMG_BLOCK=0 restores the token-by-token loop",
                           "stories_per_gpu": SPG,
                           "step_definition": "one lock-step round of the %d resident stories = %d story-steps" % (SPG, SPG),
                           "parallelism": "story replicas x%d, %d lock-step story slots per GPU" % (world, SPG)},

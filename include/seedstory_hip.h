@@ -294,6 +294,12 @@ void ss_llama_destroy(ss_llama* h);
  * kv_gather / prefill / generate address.  Slots have private KV caches, logits, token and hidden
  * rings; they share the weights and the activation scratch.  Default slot 0. */
 int ss_llama_select(ss_llama* h, int32_t seq);
+/* Optional second stop token of the decode loop (besides EOS and the token limit): generation ends right AFTER producing
+ * `token_id` (it is in the generated ids, not yet fed).  -1 = none (default).  Used to stop at `<img>`: the 64
+ * `<img_000NN>` tokens + `</img>` that follow are forced by the logits processor (generation.py:19-31), so the host
+ * feeds them as ONE batched continuation (ss_llama_prefill, weights streamed once for 66 rows instead of 66 times) and
+ * resumes the loop from its logits.  Applies to every sequence slot. */
+int ss_llama_set_stop_id(ss_llama* h, int32_t token_id);
 
 /* Device pointers into the engine's workspace (views for the Python side), for the selected slot:
  * which: 0 = K cache [n_layers, n_heads, cache_cap, hd], 1 = V cache (same shape),

@@ -63,7 +63,11 @@ __global__ __launch_bounds__(1024) void sample_embed_kernel(T* logits, int vocab
     int tok = imgproc_argmax_block<T>(logits, vocab, st[ST_LAST], img_ids, n_img_ids, sv, si);
     const int n = st[ST_NGEN];
     if (n < st[ST_NFORCED]) tok = forced[n];
-    const bool stop = (tok == st[ST_EOS]) || (n + 1 >= st[ST_LIMIT]);
+    // ST_EOS packs two stop ids: the EOS token in the low half and an optional second stop token + 1 in the high half
+    // (ss_llama_set_stop_id: the drivers stop at <img> to run the processor-forced image tokens as one batched forward)
+    const int eos_word = st[ST_EOS];
+    const int eos_id = eos_word & 0xFFFF, stop2 = (eos_word >> 16) - 1;
+    const bool stop = (tok == eos_id) || (tok == stop2) || (n + 1 >= st[ST_LIMIT]);
     __syncthreads();
     if (threadIdx.x == 0) {
         gen_ids[n] = tok;
@@ -159,6 +163,7 @@ struct ss_llama {
     int hd;
     int n_seq;               // sequence slots (independent stories sharing one sweep of the weights)
     int cur;                 // slot addressed by the single-sequence entry points
+    int stop2 = -1;          // optional second stop token of the decode loop (-1 = none), ss_llama_set_stop_id
     int64_t max_rows;
     size_t esz;
     // device buffers (carved from the caller's workspace); every per-sequence array is [n_seq][...]
@@ -420,6 +425,12 @@ void ss_llama_destroy(ss_llama* h) {
     delete h;
 }
 
+int ss_llama_set_stop_id(ss_llama* h, int32_t token_id) {
+    SS_REQUIRE(h && token_id >= -1 && token_id < 0x7FFE, "llama_set_stop_id: token id %d out of range", (int)token_id);
+    h->stop2 = token_id;
+    return SS_OK;
+}
+
 int ss_llama_select(ss_llama* h, int32_t seq) {
     SS_REQUIRE(h && seq >= 0 && seq < h->n_seq, "llama_select: sequence slot %d out of range", (int)seq);
     h->cur = seq;
@@ -553,11 +564,12 @@ static int64_t stage_seq(ss_llama* h, int b, int64_t n_steps, int32_t last_id, c
     const int64_t limit = n_steps < g.max_new ? n_steps : g.max_new;
     int64_t eff = limit;
     for (int64_t i = 0; i < n_forced && i < eff; ++i)
-        if (forced[i] == g.eos_id) { eff = i + 1; break; }  // the host already knows where it stops
+        if (forced[i] == g.eos_id || forced[i] == h->stop2) { eff = i + 1; break; }  // the host already knows where it stops
     int32_t* init = h->pinned + (size_t)h->n_seq * 8 + (size_t)b * 8;
     init[ST_KV_LEN] = (int32_t)h->kv_len[b]; init[ST_POS] = (int32_t)h->pos[b]; init[ST_NGEN] = 0;
     init[ST_DONE] = active ? 0 : 1; init[ST_LAST] = last_id; init[ST_NFORCED] = (int32_t)n_forced;
-    init[ST_LIMIT] = (int32_t)limit; init[ST_EOS] = g.eos_id;
+    init[ST_LIMIT] = (int32_t)limit;
+    init[ST_EOS] = (g.eos_id >= 0 ? (g.eos_id & 0xFFFF) : 0xFFFF) | ((h->stop2 + 1) << 16);
     return active ? eff : 0;
 }
 

@@ -102,6 +102,7 @@ PROTOTYPES = {
                                   C.POINTER(vp)]),
     "ss_llama_destroy": (None, [vp]),
     "ss_llama_select": (C.c_int, [vp, i32]),
+    "ss_llama_set_stop_id": (C.c_int, [vp, i32]),
     "ss_llama_buffer": (vp, [vp, C.c_int]),
     "ss_llama_set_lengths": (C.c_int, [vp, i64, i64, vp]),
     "ss_llama_get_lengths": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),

@@ -252,6 +252,115 @@ class LlamaEngine:
               "ss_llama_generate_batch")
         return [int(v) for v in out]
 
+    # ---- image-token block decode ---------------------------------------------------------------------------
+    # After ``<img>`` the logits processor FORCES the next 65 tokens (``<img_00000>`` .. ``<img_00063>``, ``</img>``:
+    # generation.py:19-31 sets their score to max + 10), so their forwards do not depend on one another's sampled
+    # output: the decode loop stops at ``<img>`` (ss_llama_set_stop_id), the forced block is fed as ONE batched
+    # continuation — the same layers, the same causal attention, the same hidden rows and KV entries, but the 13.2 GB
+    # of weights are streamed once for 66 rows instead of 66 times — and the loop resumes from the block's last logits.
+    # lm_head is still applied to every block row (the reference computes those logits; they cannot change a forced
+    # token), so no arithmetic of the sequential loop is skipped.
+    @staticmethod
+    def img_block_enabled():
+        """Default ON; ``SEEDSTORY_IMG_BLOCK=0`` or the ``img_block_decode`` tuning knob set to 0 restore the token-by-token loop."""
+        import os
+        return _lib.get_tuning("img_block_decode", 0 if os.environ.get("SEEDSTORY_IMG_BLOCK", "1") == "0" else 1) != 0
+
+    def set_stop_id(self, token_id):
+        check(lib().ss_llama_set_stop_id(self._h, int(token_id)), "ss_llama_set_stop_id")
+
+    def _img_block(self, remaining, forced):
+        """The slot's decode loop has just produced ``<img>`` (not fed yet).  Feeds the forced block; returns
+        (tokens appended, hidden rows [rows, H], id of the last token fed or None when the block ended the budget)."""
+        blk = self.img_ids
+        m = min(remaining, len(blk) - 1)                          # tokens the block contributes: blk[1 .. m]
+        if forced[:m] != blk[1:m + 1][:len(forced[:m])]:
+            raise _lib.SSError("forced tokens contradict the image-token schedule that follows <img>")
+        rows = m + 1 if remaining > len(blk) - 1 else m            # </img> is fed only when generation goes on after it
+        ids = torch.tensor(blk[:rows], dtype=torch.int32, device=self.device)
+        emb = ops.gather_rows(self.embed, ids)
+        step = int(self.max_rows)                                   # rows per prefill call the engine was sized for
+        hb = torch.cat([self.prefill(emb[i:i + step], want_hidden=True).clone() for i in range(0, rows, step)]) \
+            if rows > step else self.prefill(emb, want_hidden=True)
+        if _lib.get_tuning("img_block_logits", 1):
+            ops.gemm(hb, self.lm_head)                             # the reference's per-position logits (unused: forced)
+        return blk[1:m + 1], hb, (blk[rows - 1] if rows == m + 1 else None)
+
+    def generate_img_block(self, n_steps, last_prompt_id, forced=None):
+        """``generate`` with the forced image-token runs batched.  Returns (ids LongTensor [n] on the host side list,
+        hidden rows [n - 1, hidden]) — the same tokens / rows the token-by-token loop yields."""
+        if len(self.img_ids) < 3:
+            n = self.generate(n_steps, last_prompt_id, forced)
+            return self.gen_ids[:n].tolist(), self.hidden_rows[:max(n - 1, 0)]
+        boi = self.img_ids[0]
+        forced = [] if forced is None else [int(t) for t in forced]
+        ids, hid, rem, last = [], [], min(int(n_steps), 1 << 30), int(last_prompt_id)
+        self.set_stop_id(boi)
+        try:
+            while rem > 0:
+                n = self.generate(rem, last, forced)
+                g = self.gen_ids[:n].tolist()
+                ids += g
+                hid.append(self.hidden_rows[:max(n - 1, 0)].clone())
+                forced, rem = forced[n:], rem - n
+                if n == 0 or g[-1] != boi or rem == 0:
+                    break                                           # EOS, the token limit, or the budget ended at <img>
+                toks, hb, last_fed = self._img_block(rem, forced)
+                ids += toks
+                hid.append(hb)
+                forced, rem = forced[len(toks):], rem - len(toks)
+                if last_fed is None:
+                    break
+                last = last_fed
+        finally:
+            self.set_stop_id(-1)
+        return ids, torch.cat(hid)[:max(len(ids) - 1, 0)]
+
+    def generate_batch_img_block(self, n_steps, last_prompt_ids, forced=None):
+        """``generate_batch`` with the forced image-token runs batched, per slot.  Returns (ids per slot, hidden rows per
+        slot).  Slots are independent: one may be inside its block while another still writes its caption."""
+        S = self.n_seq
+        if len(self.img_ids) < 3:
+            ns = self.generate_batch(n_steps, last_prompt_ids, forced)
+            return ([self.select(b).gen_ids[:ns[b]].tolist() for b in range(S)],
+                    [self.select(b).hidden_rows[:max(ns[b] - 1, 0)] for b in range(S)])
+        boi = self.img_ids[0]
+        forced = [[] for _ in range(S)] if forced is None else [[int(t) for t in (f or [])] for f in forced]
+        ids, hid = [[] for _ in range(S)], [[] for _ in range(S)]
+        rem, last, active = [int(n_steps)] * S, [int(t) for t in last_prompt_ids], [True] * S
+        self.set_stop_id(boi)
+        try:
+            while any(active):
+                n_call = min(rem[b] for b in range(S) if active[b])
+                ns = self.generate_batch(n_call, last, forced, active)
+                for b in range(S):
+                    if not active[b]:
+                        continue
+                    n = ns[b]
+                    self.select(b)
+                    g = self.gen_ids[:n].tolist()
+                    ids[b] += g
+                    hid[b].append(self.hidden_rows[:max(n - 1, 0)].clone())
+                    forced[b], rem[b] = forced[b][n:], rem[b] - n
+                    if n == 0 or rem[b] == 0 or g[-1] == self.eos_id:
+                        active[b] = False
+                    elif g[-1] == boi:
+                        toks, hb, last_fed = self._img_block(rem[b], forced[b])
+                        ids[b] += toks
+                        hid[b].append(hb)
+                        forced[b], rem[b] = forced[b][len(toks):], rem[b] - len(toks)
+                        if last_fed is None:
+                            active[b] = False
+                        else:
+                            last[b] = last_fed
+                    else:       # stopped by this call's common limit: feed its last token, resume from fresh logits
+                        t = torch.tensor([g[-1]], dtype=torch.int32, device=self.device)
+                        hid[b].append(self.prefill(ops.gather_rows(self.embed, t), want_hidden=True))
+                        last[b] = g[-1]
+        finally:
+            self.set_stop_id(-1)
+        return ids, [torch.cat(h)[:max(len(i) - 1, 0)] for h, i in zip(hid, ids)]
+
     def profile_decode(self, n_tokens=4):
         ms = (C.c_float * 8)()
         by = (C.c_double * 4)()

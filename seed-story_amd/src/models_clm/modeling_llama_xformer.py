@@ -303,13 +303,19 @@ class LlamaForCausalLM(nn.Module):
         if max_new_tokens > eng.max_new:
             raise ValueError("max_new_tokens=%d exceeds the engine's generated-token ring (max_new=%d): raise "
                              "LlamaForCausalLM.max_new before the first generate()" % (max_new_tokens, eng.max_new))
-        n = eng.generate(max_new_tokens, int(input_ids[0, -1]), forced_tokens)
-        gen = eng.gen_ids[:n].to(torch.long)
+        if img_ids and eng.img_block_enabled():
+            # the 65 processor-forced tokens behind <img> run as one batched continuation (seedstory/llama.py)
+            gen_list, hr = eng.generate_img_block(max_new_tokens, int(input_ids[0, -1]), forced_tokens)
+            n = len(gen_list)
+            gen = torch.tensor(gen_list, dtype=torch.long, device=dev)
+        else:
+            n = eng.generate(max_new_tokens, int(input_ids[0, -1]), forced_tokens)
+            gen = eng.gen_ids[:n].to(torch.long)
+            hr = eng.hidden_rows[:max(n - 1, 0)]
         sequences = torch.cat([input_ids[0], gen]).unsqueeze(0)
         hidden_states = None
         if output_hidden_states:
             steps = [(hid0.unsqueeze(0),)]
-            hr = eng.hidden_rows[:max(n - 1, 0)]
             steps += [(hr[j].view(1, 1, -1),) for j in range(hr.shape[0])]
             hidden_states = tuple(steps)
         self.past_key_values = eng.past_key_values()

@@ -478,3 +478,69 @@ def test_forward_call_and_manual_greedy_loop(golden):
     assert g2.sequences[0, 21:].tolist() == gen_o[:8]
     with pytest.raises(ValueError):
         llm.generate(input_ids=ids, inputs_embeds=emb[ids].to(DEV), logits_processor=[proc], max_new_tokens=33)   # > max_new
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_img_block_decode_equals_token_by_token(golden, dtype, tol):
+    """The forced image-token run behind ``<img>`` fed as one batched continuation (``generate_img_block`` /
+    ``generate_batch_img_block``, ss_llama_set_stop_id) vs the token-by-token loop: identical ids, hidden rows and KV cache
+    within accumulation-order noise — single slot (two images in one call, budget ending inside a block) and four slots
+    that reach ``<img>`` at different times."""
+    from seedstory.llama import LlamaEngine
+    g, meta = golden
+    img = _img_ids(meta)
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
+    eng = LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"],
+                      dtype=dtype, device=DEV, cache_cap=256, max_new=192, max_prefill_rows=64, img_ids=img)   # ring >= every n_steps below
+    emb = wd["model.embed_tokens.weight"]
+    prompt = synth.randint(71, (19,), 3, img[0] - 1)
+
+    def run(block, n_steps, forced):
+        eng.reset()
+        eng.prefill(emb[prompt])
+        if block:
+            ids, hid = eng.generate_img_block(n_steps, int(prompt[-1]), forced)
+        else:
+            n = eng.generate(n_steps, int(prompt[-1]), forced)
+            ids, hid = eng.gen_ids[:n].tolist(), eng.hidden_rows[:n - 1].clone()
+        return ids, hid.float().cpu(), eng.lengths(), eng.k_cache[:, :, :eng.lengths()[0]].float().cpu()
+
+    cap = synth.randint(72, (5,), 3, img[0] - 1).tolist()
+    for n_steps, forced in ((100, cap + [img[0]]),                                   # caption, <img>, block, free tail
+                            (5 + 66 + 4 + 66 + 3, cap + img + cap[:3] + [img[0]]),   # two images in one call
+                            (5 + 1 + 30, cap + [img[0]])):                           # budget ends inside the block
+        a, b = run(False, n_steps, forced), run(True, n_steps, forced)
+        if dtype == torch.float32:
+            assert a[0] == b[0]
+        else:                       # bf16: the forced part is exact; a free-running tail may flip on a near-tie
+            k = 5 + 66 if n_steps >= 5 + 66 else len(a[0])
+            assert a[0][:k] == b[0][:k]
+        n = min(len(a[0]), len(b[0])) if dtype != torch.float32 else len(a[0])
+        if a[0] == b[0]:
+            assert a[2] == b[2] and a[1].shape == b[1].shape
+            assert rel(b[1], a[1]) < tol and rel(b[3], a[3]) < tol
+    # four slots, captions of different lengths (slot 2 never opens an image, slot 3 is forced through EOS)
+    e4 = LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"],
+                     dtype=dtype, device=DEV, cache_cap=256, max_new=128, max_prefill_rows=64, img_ids=img, n_seq=4)
+    prompts = [synth.randint(80 + b, (11 + 3 * b,), 3, img[0] - 1) for b in range(4)]
+    forced = [cap[:2] + [img[0]], cap + cap + [img[0]], cap + cap + cap, cap[:3] + [2]]
+    lasts = [int(p[-1]) for p in prompts]
+
+    def prefill_all():
+        for b in range(4):
+            e4.select(b).reset()
+            e4.select(b).prefill(emb[prompts[b]])
+    prefill_all()
+    ns = e4.generate_batch(80, lasts, forced)
+    seq = [(e4.select(b).gen_ids[:ns[b]].tolist(), e4.select(b).hidden_rows[:max(ns[b] - 1, 0)].float().cpu()) for b in range(4)]
+    prefill_all()
+    ids, hids = e4.generate_batch_img_block(80, lasts, forced)
+    for b in range(4):
+        fixed = len(forced[b]) + (65 if forced[b][-1] == img[0] else 0)
+        assert ids[b][:fixed] == seq[b][0][:fixed], b
+        if ids[b] == seq[b][0]:
+            assert rel(hids[b], seq[b][1]) < tol, b
+        else:
+            assert dtype != torch.float32, b
+    assert ids[3] == forced[3] and len(ids[0]) == 80 and len(ids[2]) == 80

@@ -409,3 +409,128 @@ def test_tile_table_is_data_round_trip_on_cpu(tmp_path):
     assert tune.load_table(path) == n
     assert sorted(map(tuple, tune.export_table())) == sorted(map(tuple, rows))
     assert tune.lookup(8192, 10240, 1280, _lib.SS_BF16) == hit
+
+
+class _FakeDecodeEngine:
+    """Host-side stand-in for LlamaEngine's decode primitives (generate / generate_batch / prefill / select / views) with a
+    deterministic toy "model": the next token is a hash of everything fed so far, the image-token processor rule on top
+    (generation.py:19-31), hidden row of a fed token = [position, token].  Drives the REAL bookkeeping of
+    ``generate_img_block`` / ``generate_batch_img_block`` (seedstory/llama.py) on CPU."""
+
+    def __init__(self, img_ids, n_seq=1, eos=2, max_rows=64):
+        import types
+        from seedstory.llama import LlamaEngine
+        self.img_ids, self.eos_id, self.n_seq, self.max_rows = list(img_ids), eos, n_seq, max_rows
+        self.device = torch.device("cpu")
+        self.embed = torch.arange(4096, dtype=torch.float32).unsqueeze(1)      # "embedding" of token t is [t]
+        self.lm_head = torch.zeros(8, 2)
+        self.fed = [[] for _ in range(n_seq)]
+        self.cur, self.stop2 = 0, -1
+        self._gen = [[] for _ in range(n_seq)]
+        self._hid = [torch.zeros(0, 2) for _ in range(n_seq)]
+        for name in ("_img_block", "generate_img_block", "generate_batch_img_block", "img_block_enabled"):
+            fn = LlamaEngine.__dict__[name]
+            setattr(self, name, fn.__func__ if isinstance(fn, staticmethod) else types.MethodType(fn, self))
+
+    # ---- the toy model -------------------------------------------------------------------------------------
+    def _next(self, b, last):
+        ids = self.img_ids
+        if last in ids[:-1]:
+            return ids[ids.index(last) + 1]
+        h = 17
+        for t in self.fed[b]:
+            h = (h * 31 + t) % 1000003
+        t = 3 + h % 200
+        return ids[0] if h % 23 == 0 else t                                      # now and then the model opens an image
+
+    def _feed(self, b, tok):
+        self.fed[b].append(tok)
+        return torch.tensor([[float(len(self.fed[b]) - 1), float(tok)]])
+
+    # ---- engine surface used by the mixin methods ------------------------------------------------------------
+    def set_stop_id(self, t):
+        self.stop2 = int(t)
+
+    def select(self, b):
+        self.cur = b
+        return self
+
+    @property
+    def gen_ids(self):
+        return torch.tensor(self._gen[self.cur], dtype=torch.int32)
+
+    @property
+    def hidden_rows(self):
+        return self._hid[self.cur]
+
+    def prefill(self, embeds, pos_ids=None, want_hidden=False):
+        rows = [self._feed(self.cur, int(v)) for v in embeds[:, 0].tolist()]
+        assert len(rows) <= self.max_rows
+        return torch.cat(rows)
+
+    def _loop(self, b, n_steps, last, forced):
+        gen, hid = [], []
+        for i in range(n_steps):
+            tok = forced[i] if i < len(forced) else self._next(b, last)
+            gen.append(tok)
+            stop = tok == self.eos_id or tok == self.stop2 or i + 1 >= n_steps
+            if stop:
+                break
+            hid.append(self._feed(b, tok))
+            last = tok
+        self._gen[b], self._hid[b] = gen, (torch.cat(hid) if hid else torch.zeros(0, 2))
+        return len(gen)
+
+    def generate(self, n_steps, last_prompt_id, forced=None):
+        return self._loop(self.cur, n_steps, last_prompt_id, list(forced or []))
+
+    def generate_batch(self, n_steps, lasts, forced=None, active=None):
+        forced = forced or [[] for _ in range(self.n_seq)]
+        return [self._loop(b, n_steps, lasts[b], list(forced[b] or [])) if (active is None or active[b]) else 0
+                for b in range(self.n_seq)]
+
+
+def test_img_block_decode_bookkeeping_on_a_toy_model(monkeypatch):
+    """Block decode of the forced image-token run == the token-by-token loop, on every path of the host bookkeeping:
+    several images per call, budgets that end before / inside / right after a block, forced prefixes that cover the block,
+    EOS, prefill chunking, and lock-step slots that diverge (common-limit feed)."""
+    from seedstory import _lib, ops
+    _lib.lib()
+    monkeypatch.setattr(ops, "gather_rows", lambda table, ids: table[ids.long()])
+    monkeypatch.setattr(ops, "gemm", lambda a, w, **kw: a @ w.t())
+    img = list(range(3000, 3066))
+    cases = 0
+    for seed_prompt in ([5, 6, 7], [9], [11, 12, 13, 14, 15, 16]):
+        for n_steps in (1, 2, 7, 40, 66, 67, 68, 131, 200, 400):
+            for forced in ([], [50, 51, img[0]], [50] + img + [2], [img[0]], [50, 51, img[0]] + img[1:10], [60, 2]):
+                ref = _FakeDecodeEngine(img)
+                ref.prefill(ref.embed[torch.tensor(seed_prompt)])
+                n = ref.generate(n_steps, seed_prompt[-1], forced)
+                want_ids, want_hid, want_fed = ref.gen_ids.tolist(), ref.hidden_rows, list(ref.fed[0])
+                eng = _FakeDecodeEngine(img)
+                eng.prefill(eng.embed[torch.tensor(seed_prompt)])
+                ids, hid = eng.generate_img_block(n_steps, seed_prompt[-1], forced)
+                assert ids == want_ids and n == len(ids), (seed_prompt, n_steps, forced)
+                assert torch.equal(hid, want_hid) and eng.fed[0] == want_fed and eng.stop2 == -1
+                cases += 1
+    assert cases == 180
+    with pytest.raises(_lib.SSError):          # a forced list that contradicts the processor inside the block
+        eng = _FakeDecodeEngine(img)
+        eng.prefill(eng.embed[torch.tensor([5])])
+        eng.generate_img_block(100, 5, [img[0], 77])
+    # slots
+    for n_steps in (3, 30, 70, 150):
+        prompts = [[5, 6], [7], [8, 9, 10], [11]]
+        forced = [[40, img[0]], [41, 42, 43, 44, 45, 46, img[0]], [], [47, 2]]
+        ref = _FakeDecodeEngine(img, n_seq=4)
+        for b in range(4):
+            ref.select(b).prefill(ref.embed[torch.tensor(prompts[b])])
+        ns = ref.generate_batch(n_steps, [p[-1] for p in prompts], forced)
+        want = [(ref.select(b).gen_ids.tolist(), ref.select(b).hidden_rows, list(ref.fed[b])) for b in range(4)]
+        eng = _FakeDecodeEngine(img, n_seq=4)
+        for b in range(4):
+            eng.select(b).prefill(eng.embed[torch.tensor(prompts[b])])
+        ids, hids = eng.generate_batch_img_block(n_steps, [p[-1] for p in prompts], forced)
+        for b in range(4):
+            assert ids[b] == want[b][0] and len(ids[b]) == ns[b], (n_steps, b)
+            assert torch.equal(hids[b], want[b][1]) and eng.fed[b] == want[b][2], (n_steps, b)
