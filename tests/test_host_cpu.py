@@ -534,3 +534,60 @@ def test_img_block_decode_bookkeeping_on_a_toy_model(monkeypatch):
         for b in range(4):
             assert ids[b] == want[b][0] and len(ids[b]) == ns[b], (n_steps, b)
             assert torch.equal(hids[b], want[b][1]) and eng.fed[b] == want[b][2], (n_steps, b)
+
+
+def test_llm_generate_assembles_block_and_sequential_runs_identically(monkeypatch):
+    """``LlamaForCausalLM.generate`` (the mirror's glue around the engine): sequences, per-step hidden_states, the cache
+    bookkeeping attributes and the ``max_new_tokens`` guard are the same whether the forced image-token run is decoded as one
+    block or token by token — driven on CPU with the toy engine above."""
+    from seedstory import _lib, ops
+    from src.models_clm.generation import AutoImageTokenGenerationProcessor
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    _lib.lib()
+    monkeypatch.setattr(ops, "gather_rows", lambda table, ids: table[ids.long()])
+    monkeypatch.setattr(ops, "gemm", lambda a, w, **kw: a @ w.t())
+    img = list(range(3000, 3066))
+
+    class Eng(_FakeDecodeEngine):
+        max_new = 512
+
+        def reset(self):
+            self.fed[0] = []
+
+        def lengths(self):
+            return (len(self.fed[0]), len(self.fed[0]))
+
+        def set_lengths(self, kv, pos):
+            self.fed[0] = self.fed[0][:kv]
+
+        def load_past_key_values(self, past):
+            self.fed[0] = list(past)
+
+        def past_key_values(self):
+            return tuple(self.fed[0])
+
+    class Tok:
+        def encode(self, s, add_special_tokens=False):
+            return list(img)
+
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEEDSTORY_IMG_BLOCK", mode)
+        m = LlamaForCausalLM(LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=1, vocab_size=50))
+        eng = Eng(img)
+        monkeypatch.setattr(m, "engine_for_generation", lambda ids, eng=eng: eng)
+        proc = [AutoImageTokenGenerationProcessor(tokenizer=Tok())]
+        ids = torch.tensor([[1, 40, 41, 42]])
+        emb = ids.float().unsqueeze(-1)
+        m.use_kv_cache_head, m.kv_cache_head = True, None
+        o = m.generate(input_ids=ids, inputs_embeds=emb, logits_processor=proc, max_new_tokens=120, forced_tokens=[60, 61, img[0]])
+        assert eng.img_block_enabled() == (mode == "1")
+        outs[mode] = (o.sequences.tolist(), torch.cat([h[0].reshape(-1, 2) for h in o.hidden_states[1:]]), m.kv_cache_head,
+                      m.past_key_values, o.hidden_states[0][0].shape)
+        with pytest.raises(ValueError):
+            m.generate(input_ids=ids, inputs_embeds=emb, logits_processor=proc, max_new_tokens=513)
+    a, b = outs["1"], outs["0"]
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    seq = a[0][0]
+    assert seq[:4] == [1, 40, 41, 42] and seq[4:7] == [60, 61, img[0]] and seq[7:7 + 65] == img[1:] and len(seq) == 4 + 120
+    assert a[2] == 4 + 119 and len(a[3]) == 4 + 119            # everything but the last generated token is cached
