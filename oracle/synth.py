@@ -22,24 +22,46 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def uniform01(seed: int, n: int, stream: int = 0) -> np.ndarray:
-    """n float64 values in [0,1), 24 bits each (exact in fp32)."""
+def uniform01(seed: int, n: int, stream: int = 0, start: int = 0) -> np.ndarray:
+    """n float64 values in [0,1), 24 bits each (exact in fp32), for flat indices [start, start+n)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(n, dtype=np.uint64)
+        idx = np.arange(start, start + n, dtype=np.uint64)
         key = _splitmix64(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
         bits = _splitmix64(idx ^ key)
     return (bits >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
 
 
-def normal_like(seed: int, shape, std: float = 0.02, mean: float = 0.0, dtype=torch.float32) -> torch.Tensor:
-    """Irwin-Hall(4) approximation of N(mean, std) — deterministic everywhere."""
-    n = int(np.prod(shape))
+_CHUNK = 1 << 21
+
+
+def _normal_chunk(seed, start, n, std, mean):
     s = np.zeros(n, dtype=np.float64)
     for k in range(4):
-        s += uniform01(seed, n, stream=k + 1)
+        s += uniform01(seed, n, stream=k + 1, start=start)
     # sum of 4 U(0,1): mean 2, var 4/12
-    z = (s - 2.0) * (std / np.sqrt(4.0 / 12.0)) + mean
-    return torch.from_numpy(z.astype(np.float32)).reshape(tuple(shape)).to(dtype)
+    return ((s - 2.0) * (std / np.sqrt(4.0 / 12.0)) + mean).astype(np.float32)
+
+
+def normal_like(seed: int, shape, std: float = 0.02, mean: float = 0.0, dtype=torch.float32) -> torch.Tensor:
+    """Irwin-Hall(4) approximation of N(mean, std) — deterministic everywhere.  Every value is a pure function of
+    (seed, flat index), so large tensors are filled chunk by chunk on a thread pool (numpy releases the GIL) with
+    bit-identical results to the single-pass evaluation."""
+    n = int(np.prod(shape))
+    if n <= _CHUNK:
+        z = _normal_chunk(seed, 0, n, std, mean)
+    else:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        z = np.empty(n, dtype=np.float32)
+        starts = list(range(0, n, _CHUNK))
+
+        def work(st):
+            m = min(_CHUNK, n - st)
+            z[st:st + m] = _normal_chunk(seed, st, m, std, mean)
+
+        with ThreadPoolExecutor(max_workers=max(1, min(32, os.cpu_count() or 1))) as ex:
+            list(ex.map(work, starts))
+    return torch.from_numpy(z).reshape(tuple(shape)).to(dtype)
 
 
 def uniform(seed: int, shape, lo: float = 0.0, hi: float = 1.0, dtype=torch.float32) -> torch.Tensor:

@@ -157,3 +157,45 @@ def test_vit_block_full_width(golden):
     y = O.vit_block_forward(wd, "", x, c["heads"])[0]
     assert rel(y[::c["row_stride"]], g["vitblk_f32.y_rows"]) < 2e-6
     assert abs(float(y.norm()) / float(g["vitblk_f32.y_norm"]) - 1) < 1e-6
+
+
+# ---- full-dimension fixtures (oracle/make_golden_full.py): the restatement against rows of the REAL reference -------------
+
+def _full():
+    import json
+    import os
+    from safetensors.torch import load_file
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(root, "frontend_full.json")) as f:
+        meta = json.load(f)
+    return load_file(os.path.join(root, "frontend_full.safetensors")), meta
+
+
+def _rows(y, stride):
+    return y.reshape(-1, y.shape[-1])[::stride]
+
+
+def test_full_dimension_resamplers_vit_ends_xlv2_fp32():
+    """Resampler 4096 / 32 heads (input and output = the regressor), ViT-G ends at 448^2 / 1664 / 4096, ResamplerXLV2 at
+    the de-tokenizer's configuration: oracle == REAL reference rows, fp32, 2e-6."""
+    g, meta = _full()
+    for tag, key in (("res_in", "RES_IN"), ("res_out", "RES_OUT")):
+        c = meta[key]
+        wd = synth.resampler_weights(c["seed"], "", c["grid"], c["embed"])
+        x = synth.normal_like(c["seed"] + 100, (c["batch"], c["n_kv"], c["embed"]), 1.0)
+        y = O.resampler_forward(wd, "", x, c["heads"])
+        assert rel(_rows(y, c["row_stride"]), g[tag + "_f32.rows"]) < 2e-6
+        assert abs(float(y.norm()) - float(g[tag + "_f32.norm"])) < 1e-5 * float(g[tag + "_f32.norm"])
+    c = meta["VIT"]
+    wd = synth.vit_weights(c["seed"], c["width"], c["layers"], c["heads"], c["mlp_width"], c["patch"], c["out_dim"],
+                           c["n_queries"])
+    x = synth.normal_like(c["seed"] + 100, (1, 3, c["image"], c["image"]), 1.0)
+    y = O.vit_forward(wd, x, width=c["width"], layers=c["layers"], heads=c["heads"], patch=c["patch"],
+                      out_dim=c["out_dim"], n_queries=c["n_queries"])
+    assert rel(_rows(y, c["row_stride"]), g["vit_f32.rows"]) < 2e-6
+    c, r = meta["XLV2"], meta["XLV2_RUN"]
+    wd = synth.resampler_xlv2_weights(r["seed"], **c)
+    x = synth.normal_like(r["seed"] + 100, (r["batch"], r["tokens"], c["embedding_dim"]), 1.0)
+    ctx, pooled = O.resampler_xlv2_forward(wd, x, depth=c["depth"], heads=c["heads"], dim_head=c["dim_head"])
+    assert rel(_rows(ctx, r["row_stride"]), g["xlv2_ctx_f32.rows"]) < 2e-6
+    assert rel(pooled, g["xlv2_pooled_f32.rows"]) < 2e-6
