@@ -87,9 +87,11 @@ int ss_gemm_fp8(const void* A8, const float* scale_a, const void* W8, const floa
                 int64_t K, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, void* stream);
 
 /* Device context ("no hidden global state except a per-device handle").  A process drives one GPU; the
- * library's only state besides the thread-local error string — the tuning knobs and the GEMM tile table — belongs to
- * that device.  ss_create validates `device` (gfx950 only), makes it the current HIP device and returns the handle that
- * owns this state; ss_destroy drops the tile table.  Op entry points act on the current HIP device and take no handle.
+ * library's only state besides the thread-local error string — the tuning knobs and the GEMM tile table — is
+ * process-global and valid for any gfx950 device (the only architecture accepted).  ss_create validates `device`, makes
+ * it the current HIP device and returns a handle; ss_destroy releases the handle and leaves the tile table alone (other
+ * users of the library in the process keep their tuned tiles; ss_tune_clear drops it explicitly).  Op entry points act
+ * on the current HIP device and take no handle.
  * ss_context_info: out = {device ordinal, CU count, HBM bytes}. */
 typedef struct ss_context ss_context;
 int ss_create(int device, ss_context** out);
@@ -298,7 +300,9 @@ int ss_llama_select(ss_llama* h, int32_t seq);
  * `token_id` (it is in the generated ids, not yet fed).  -1 = none (default).  Used to stop at `<img>`: the 64
  * `<img_000NN>` tokens + `</img>` that follow are forced by the logits processor (generation.py:19-31), so the host
  * feeds them as ONE batched continuation (ss_llama_prefill, weights streamed once for 66 rows instead of 66 times) and
- * resumes the loop from its logits.  Applies to every sequence slot. */
+ * resumes the loop from its logits.  Applies to every sequence slot.  Range: -1 <= token_id < min(vocab, 32766) — the
+ * loop's stop word holds EOS in 16 bits and this id + 1 in the 15 bits above; ss_llama_create therefore requires
+ * vocab <= 65535 and eos_id < 65535 (LLaMA-2 + 66 added tokens: 32066). */
 int ss_llama_set_stop_id(ss_llama* h, int32_t token_id);
 
 /* Device pointers into the engine's workspace (views for the Python side), for the selected slot:

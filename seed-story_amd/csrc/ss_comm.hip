@@ -87,8 +87,6 @@ bool rccl_dtype(int dtype, ncclDataType_t* out) {
 
 extern "C" {
 
-int ss_tune_clear(void);
-
 int ss_create(int device, ss_context** out) {
     SS_REQUIRE(out, "ss_create: out == NULL");
     *out = nullptr;
@@ -112,8 +110,9 @@ int ss_context_info(const ss_context* ctx, int64_t out[3]) {
 }
 
 void ss_destroy(ss_context* ctx) {
-    if (!ctx) return;
-    ss_tune_clear();     // the tile table was measured on this device
+    // The GEMM tile table is process-global (ops take no context handle) and every entry in it was measured on gfx950,
+    // the only architecture ss_create accepts — it outlives a context: other users of the library in this process keep
+    // their tuned tiles.  ss_tune_clear() is the explicit way to drop it.
     delete ctx;
 }
 

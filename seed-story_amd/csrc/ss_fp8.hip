@@ -26,17 +26,28 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restr
     const T* xr = x + (int64_t)row * ld;
     float mean = 0.f, rstd = 1.f;
     if constexpr (LN) {
-        float s = 0.f, ss2 = 0.f;
+        // two-pass statistics like layernorm_wave_kernel / ss_rowstats (mean, then sum of squared deviations): the
+        // single-pass E[x^2] - mean^2 form cancels on rows with |mean| >> std (outlier channels of UNet hidden states)
+        float s = 0.f;
         for (int k = lane * 8; k < K; k += 512) {
             float f[8];
             unpack<T>(*reinterpret_cast<const uint4*>(xr + k), f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s += f[e]; ss2 += f[e] * f[e]; }
+            for (int e = 0; e < 8; ++e) s += f[e];
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss2 += __shfl_xor(ss2, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         mean = s / (float)K;
-        const float var = fmaxf(ss2 / (float)K - mean * mean, 0.f);
+        float ss2 = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {      // the row is re-read from L1/L2
+            float f[8];
+            unpack<T>(*reinterpret_cast<const uint4*>(xr + k), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; ss2 += d * d; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss2 += __shfl_xor(ss2, o, 64);
+        const float var = ss2 / (float)K;
         rstd = rsqrtf(var + eps);
     }
     auto value = [&](const float (&f)[8], int k, float (&o)[8]) {

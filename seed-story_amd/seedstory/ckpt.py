@@ -8,7 +8,8 @@
   de-tokenizer ``pytorch_model.bin``  torch pickle; ``unet.*`` (diffusers names) + ``resampler.*``  (adapter_modules.py:350-357)
   SDXL-base diffusers folder       ``unet/``, ``vae/`` (config.json + diffusion_pytorch_model.safetensors), ``scheduler/``
   HF LLaMA folder                  config.json + (sharded) ``*.safetensors`` / ``pytorch_model-*.bin``
-  peft adapter folder              adapter_config.json + adapter_model.bin (adapter name stripped from the keys)
+  peft adapter folder              adapter_config.json + adapter_model.bin (``.default`` AND ``modules_to_save.`` stripped
+                                   from the keys by peft's save path)
 
 The reference loads all of them with ``strict=False`` and prints only COUNTS, which hides key mismatches; `load_checked`
 keeps that behaviour (same print) but records the names on the module (``model.load_report``) and warns with the first
@@ -47,17 +48,32 @@ def load_checked(model, state_dict, tag, expect_unexpected=()):
     return model.load_report
 
 
-def peft_adapter_to_wrapper_keys(sd, adapter_name="default"):
-    """Keys of a SAVED peft==0.4.0 adapter (``get_peft_model_state_dict`` strips ``.<adapter_name>``) back to the
-    wrapper's live names (``set_peft_model_state_dict``): ``lora_A.weight`` -> ``lora_A.default.weight`` and
-    ``modules_to_save.weight`` -> ``modules_to_save.default.weight``."""
+def peft_adapter_to_wrapper_keys(sd, adapter_name="default", modules_to_save=None):
+    """Keys of a SAVED peft==0.4.0 adapter back to the wrapper's live names, the way ``set_peft_model_state_dict`` does it.
+
+    ``get_peft_model_state_dict`` strips BOTH ``modules_to_save.`` and ``.<adapter_name>`` on save, so on disk a LoRA factor
+    is ``….q_proj.lora_A.weight`` and a ``modules_to_save`` copy is just ``….input_layernorm.weight``.  Loading re-inserts
+    ``<module>.modules_to_save.<adapter>`` for the FIRST name of ``config.modules_to_save`` that occurs in the key
+    (substring match, list order — ``norm`` is also a substring of ``input_layernorm``, which is why order matters) and
+    ``.<adapter>`` behind ``lora_A`` / ``lora_B`` / ``lora_embedding_*``."""
     out = {}
+    mts = list(modules_to_save or ())
     for k, v in sd.items():
-        for leaf in ("lora_A", "lora_B", "lora_embedding_A", "lora_embedding_B", "modules_to_save"):
-            tok = "." + leaf + "."
-            if tok in k and (tok + adapter_name + ".") not in k:
-                k = k.replace(tok, tok + adapter_name + ".")
-                break
+        if mts and "modules_to_save" not in k and "lora_" not in k:
+            for name in mts:
+                if name in k:
+                    k = k.replace(name, "%s.modules_to_save.%s" % (name, adapter_name))
+                    break
+        elif ".modules_to_save." in k and (".modules_to_save." + adapter_name + ".") not in k:
+            k = k.replace(".modules_to_save.", ".modules_to_save." + adapter_name + ".")      # tolerated older layout
+        if "lora_" in k:
+            suffix = k.split("lora_")[1]
+            if "." in suffix:
+                rest = ".".join(suffix.split(".")[1:])
+                if not rest.startswith(adapter_name + "."):
+                    k = k[:len(k) - len(rest)] + adapter_name + "." + rest
+            else:
+                k = k + "." + adapter_name
         out[k] = v
     return out
 
@@ -65,4 +81,4 @@ def peft_adapter_to_wrapper_keys(sd, adapter_name="default"):
 def read_peft_adapter(folder):
     with open(os.path.join(folder, "adapter_config.json")) as f:
         cfg = json.load(f)
-    return cfg, peft_adapter_to_wrapper_keys(read_weights(folder))
+    return cfg, peft_adapter_to_wrapper_keys(read_weights(folder), modules_to_save=cfg.get("modules_to_save"))

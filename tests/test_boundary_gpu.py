@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_context_create_info_destroy_owns_tile_table():
+def test_context_create_info_destroy_keeps_tile_table():
     from seedstory import _lib, comm, tune
     with pytest.raises(_lib.SSError):
         comm.Context(99)
@@ -16,10 +16,11 @@ def test_context_create_info_destroy_owns_tile_table():
     info = ctx.info()
     assert info["device"] == 0 and info["cu_count"] == 256 and info["hbm_bytes"] > 200 * 2 ** 30
     tune.load_default_table()
-    assert len(tune.export_table()) > 0
+    n = len(tune.export_table())
+    assert n > 0
     ctx.close()
-    assert len(tune.export_table()) == 0           # the table belongs to the handle's device
-    tune.load_default_table()                      # restore for the tests that follow in this process
+    # the tile table is process-global (ops take no handle): other users of the library keep their tuned tiles
+    assert len(tune.export_table()) == n
 
 
 def test_rccl_single_rank_bcast_and_argument_errors():

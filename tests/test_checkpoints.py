@@ -158,7 +158,9 @@ def test_peft_adapter_folder(golden, tmp_path):
     d = meta["LLAMA"]
     wd = synth.llama_weights(12, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], lora_r=16)
     live = peft_layout(wd, with_base=False, with_original=False)
-    saved = {k.replace(".default.", "."): v for k, v in live.items()}       # get_peft_model_state_dict strips the name
+    # peft 0.4.0 get_peft_model_state_dict: `key.replace("modules_to_save.", "")` then `.replace(".default", "")`
+    saved = {k.replace("modules_to_save.", "").replace(".default", ""): v for k, v in live.items()}
+    assert any(k.endswith("input_layernorm.weight") for k in saved) and not any("modules_to_save" in k for k in saved)
     folder = tmp_path / "adapter"
     folder.mkdir()
     json.dump(LORA_CFG, open(folder / "adapter_config.json", "w"))

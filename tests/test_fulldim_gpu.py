@@ -476,6 +476,111 @@ def test_vae_decode_full_size_pixel_parity():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# (c2) the ASSEMBLED SDXL-base UNet (2.57 B parameters, 128^2 latents, CFG batch 2) vs the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sdxl_full_truth(sdxl_unet_bf16):
+    """fp32 CPU oracle on the bf16-representable weights of the module fixture: eps of the first Euler step (one UNet
+    forward at batch 2 = [uncond; cond]), the latents after two Euler+CFG steps (`S.sdxl_generate_latents` unrolled so
+    that the first forward is shared), and the bf16 oracle forward.  Three CPU forwards of 13.5 TFLOP each."""
+    import time
+    import sdxl_oracle as S
+    c = S.SDXL_BASE_UNET
+    wd = {k: v.detach().float().cpu() for k, v in sdxl_unet_bf16.state_dict().items()}
+    inp = dict(noise=synth.normal_like(71, (1, 4, 128, 128), 1.0), ctx_pos=synth.normal_like(72, (1, 64, 2048), 1.0),
+               ctx_neg=synth.normal_like(73, (1, 64, 2048), 1.0), pooled_pos=synth.normal_like(74, (1, 1280), 1.0),
+               pooled_neg=synth.normal_like(75, (1, 1280), 1.0))
+    inp = {k: v.to(torch.bfloat16).float() for k, v in inp.items()}            # both sides see bf16-representable inputs
+    ts, sig, init = S.euler_schedule(2)
+    ids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)
+    ctx = torch.cat([inp["ctx_neg"], inp["ctx_pos"]], 0)
+    pooled = torch.cat([inp["pooled_neg"], inp["pooled_pos"]], 0)
+    x = inp["noise"] * init
+    out = dict(inp=inp, ts=ts, sig=sig, init=init, ids=ids, ctx=ctx, pooled=pooled)
+    t0 = time.time()
+    with torch.no_grad():
+        xin0 = torch.cat([x, x], 0) / math.sqrt(sig[0] ** 2 + 1.0)
+        out["xin0"] = xin0
+        eps0 = S.unet_forward(wd, c, xin0, float(ts[0]), ctx, pooled, ids)
+        out["eps0"] = eps0
+        t1 = time.time()
+        e_neg, e_pos = eps0.chunk(2)
+        x = x + (e_neg + 7.5 * (e_pos - e_neg)) * (sig[1] - sig[0])
+        out["x1"] = x
+        xin1 = torch.cat([x, x], 0) / math.sqrt(sig[1] ** 2 + 1.0)
+        e_neg, e_pos = S.unet_forward(wd, c, xin1, float(ts[1]), ctx, pooled, ids).chunk(2)
+        out["x2"] = x + (e_neg + 7.5 * (e_pos - e_neg)) * (sig[2] - sig[1])
+        t2 = time.time()
+        bf = torch.bfloat16
+        wbf = {k: v.to(bf) for k, v in wd.items()}
+        out["eps0_bf16"] = S.unet_forward(wbf, c, xin0.to(bf), float(ts[0]), ctx.to(bf), pooled.to(bf), ids).float()
+    print("CPU oracle, SDXL-base UNet batch 2 at 128^2: fp32 forward %.1f s, second %.1f s, bf16 forward %.1f s (%d threads)"
+          % (t1 - t0, t2 - t1, time.time() - t2, torch.get_num_threads()))
+    return out
+
+
+def test_sdxl_unet_assembled_full_size_fp32(sdxl_unet_bf16, sdxl_full_truth):
+    """The whole network in the library's exact-fp32 MFMA mode vs `sdxl_oracle.unet_forward` in fp32 on the same
+    weights: skip-concat order, down / up samplers, the stacked time-embedding GEMM, the add-embedding, 70 transformer
+    blocks and 17+ ResBlocks composed (adapter_modules.py:455-466 -> UNet2DConditionModel.forward); then two Euler + CFG
+    steps of the pipeline vs the oracle's `sdxl_generate_latents` arithmetic."""
+    from seedstory.diffusion import EulerDiscreteScheduler, StableDiffusionXLPipeline, UNet2DConditionModel
+    T = sdxl_full_truth
+    m32 = UNet2DConditionModel().to(DEV, torch.float32)
+    m32.load_state_dict({k: v.float() for k, v in sdxl_unet_bf16.state_dict().items()})
+    eps = m32(T["xin0"].to(DEV), float(T["ts"][0]), T["ctx"].to(DEV),
+              added_cond_kwargs={"text_embeds": T["pooled"].to(DEV), "time_ids": T["ids"]}).sample
+    assert eps.shape == T["eps0"].shape == (2, 4, 128, 128)
+    e = rel(eps, T["eps0"])
+    print("assembled SDXL-base UNet, fp32 (exact-fp32 MFMA) vs CPU oracle fp32: eps rel %.3e" % e)
+    assert e < 1e-3
+    pipe = StableDiffusionXLPipeline(vae=None, unet=m32, scheduler=EulerDiscreteScheduler())
+    i = T["inp"]
+    x2 = pipe(prompt_embeds=i["ctx_pos"].to(DEV), negative_prompt_embeds=i["ctx_neg"].to(DEV),
+              pooled_prompt_embeds=i["pooled_pos"].to(DEV), negative_pooled_prompt_embeds=i["pooled_neg"].to(DEV),
+              guidance_scale=7.5, num_inference_steps=2, latents=i["noise"].to(DEV), output_type="latent").images
+    e2 = rel(x2, T["x2"])
+    print("two Euler + CFG steps (pipeline, fp32) vs oracle latents: rel %.3e" % e2)
+    assert e2 < 1e-3
+    del m32, pipe
+    torch.cuda.empty_cache()
+
+
+def test_sdxl_unet_assembled_full_size_bf16(sdxl_unet_bf16, sdxl_full_truth):
+    """The shipped bf16 network vs the fp32 truth, gated by the oracle's OWN bf16-vs-fp32 distance (1.5x), plus the
+    pipeline's two Euler + CFG steps and hipGraph replay == eager at full size."""
+    from seedstory import _lib
+    from seedstory.diffusion import EulerDiscreteScheduler, StableDiffusionXLPipeline
+    T = sdxl_full_truth
+    m, bf = sdxl_unet_bf16, torch.bfloat16
+    eps = m(T["xin0"].to(DEV, bf), float(T["ts"][0]), T["ctx"].to(DEV, bf),
+            added_cond_kwargs={"text_embeds": T["pooled"].to(DEV, bf), "time_ids": T["ids"]}).sample
+    e_bf, e_32, theirs = rel(eps, T["eps0_bf16"]), rel(eps, T["eps0"]), rel(T["eps0_bf16"], T["eps0"])
+    print("assembled SDXL-base UNet bf16: HIP vs oracle-bf16 %.3e | HIP vs oracle-fp32 %.3e | oracle bf16 vs fp32 %.3e"
+          % (e_bf, e_32, theirs))
+    assert e_32 <= 1.5 * theirs + 2e-3
+    assert e_bf <= 2.5 * theirs + 2e-3
+    pipe = StableDiffusionXLPipeline(vae=None, unet=m, scheduler=EulerDiscreteScheduler())
+    i = {k: v.to(DEV, bf) for k, v in T["inp"].items()}
+    kw = dict(prompt_embeds=i["ctx_pos"], negative_prompt_embeds=i["ctx_neg"], pooled_prompt_embeds=i["pooled_pos"],
+              negative_pooled_prompt_embeds=i["pooled_neg"], guidance_scale=7.5, latents=i["noise"], output_type="latent")
+    x2 = pipe(num_inference_steps=2, **kw).images
+    e2 = rel(x2, T["x2"])
+    print("two Euler + CFG steps (pipeline, bf16) vs oracle fp32 latents: rel %.3e" % e2)
+    assert e2 <= 3.0 * theirs + 5e-3          # CFG amplifies the eps error by up to the guidance scale; latents are O(10)
+    # hipGraph replay (steps 1..n-1 of a 4-step render) == the eager loop, same binary, full size
+    xg = pipe(num_inference_steps=4, **kw).images
+    _lib.set_tuning("unet_graph", 0)
+    try:
+        xe = pipe(num_inference_steps=4, **kw).images
+    finally:
+        _lib.set_tuning("unet_graph", 1)
+    eg = rel(xg, xe)
+    print("4-step render, hipGraph replay vs eager: rel %.3e" % eg)
+    assert eg < 2e-2      # GroupNorm statistics are fp64 atomics: order-dependent in the last bit, amplified by 70 blocks
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # (d) bf16 ContinuousLVLM.generate vs the reference's own bf16 CPU run
 # ---------------------------------------------------------------------------------------------------------------------
 class _Tok:

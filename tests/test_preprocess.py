@@ -73,6 +73,7 @@ def test_host_transform_is_pil_plus_torch_ops():
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs the MI355X (the rest of this file runs on CPU)")
 @pytest.mark.parametrize("kind,keep_ratio,size,h,w", [("clip", False, 448, 300, 200), ("clip", False, 448, 1024, 1024),
                                                       ("clip", True, 224, 517, 733), ("sd", True, 256, 333, 500),
                                                       ("clipa", False, 448, 448, 448), ("sd", False, 128, 97, 1500)])
