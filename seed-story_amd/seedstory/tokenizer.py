@@ -6,8 +6,11 @@ default ``legacy=True`` mode) and uses exactly four things of it: ``encode(text,
 (gen_george.py:104-105,174,233), ``bos_token_id`` (:175), ``decode(ids, skip_special_tokens=False)``
 (models.py:156) and ``__call__(prompt, return_tensors='pt').input_ids`` (models.py:119-121).  The transformers in this
 image (5.x) replaced that class with a `tokenizers`-backed one whose behaviour around added tokens differs, so the
-four calls are restated here directly on the sentencepiece model — parity with 4.34 is UNPINNED (transformers 4.34 and
-the tokenizer folder are both absent); the behaviour below follows its published source:
+four calls are restated here directly on the sentencepiece model.  Parity with 4.34 itself is unpinned (4.34 and the
+tokenizer folder are both absent); against the INSTALLED transformers 5.15 the ids of every driver-shaped string are
+pinned on a LLaMA-like sentencepiece model (tests/test_prompt_cpu.py::test_tokenizer_pinned_on_installed_transformers,
+which also states the two places where 5.15 departs from 4.34-slow).  The behaviour below follows 4.34's published
+source:
 
   encode   the text is split on the added tokens (longest match, left to right; nothing stripped around them); every
            other non-empty segment is sentencepiece-encoded on its own — so, in legacy mode, EVERY segment gets the

@@ -544,3 +544,46 @@ def test_img_block_decode_equals_token_by_token(golden, dtype, tol):
         else:
             assert dtype != torch.float32, b
     assert ids[3] == forced[3] and len(ids[0]) == 80 and len(ids[2]) == 80
+
+
+class _ProcStub:
+    """Carries the 66 image-token ids the way AutoImageTokenGenerationProcessor does (generation.py:17)."""
+
+    def __init__(self, ids):
+        self.img_ids_list = list(ids)
+
+
+@pytest.mark.parametrize("case", ["free", "eos"])
+def test_llm_generate_vs_real_hf_generate(case):
+    """``LlamaForCausalLM.generate`` (device greedy loop + image-token block decode) against a REAL
+    ``GenerationMixin.generate`` run with the reference's logits processor (tests/golden/greedy_hf.*, written by
+    oracle/make_golden_greedy.py with the installed transformers 5.15; the reference pins 4.34): generated ids — the 65
+    processor-forced tokens and the free-running tail — the EOS stop, and the last-layer hidden rows."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = load_file(os.path.join(root, "greedy_hf.safetensors"))
+    with open(os.path.join(root, "greedy_hf.json")) as f:
+        meta = json.load(f)
+    d = meta["LLAMA"]
+    eos = 2 if case == "free" else meta["eos_case_id"]
+    cfg = LlamaConfig(hidden_size=d["hidden"], intermediate_size=d["inter"], num_hidden_layers=d["n_layers"],
+                      num_attention_heads=d["n_heads"], vocab_size=d["vocab"], eos_token_id=eos)
+    llm = LlamaForCausalLM(cfg)
+    missing, unexpected = llm.load_state_dict(synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"],
+                                                                  d["vocab"]), strict=False)
+    assert not missing and not unexpected
+    llm.cache_cap, llm.max_new, llm.max_prefill_rows = 256, 128, 128
+    llm.use_kv_cache_head = False
+    llm = llm.to(DEV)
+    img_ids = list(range(meta["IMG_IDS"][0], meta["IMG_IDS"][1] + 1))
+    S = g["input_ids"].shape[1]
+    out = llm.generate(input_ids=g["input_ids"], inputs_embeds=g["inputs_embeds"].to(DEV), logits_processor=[_ProcStub(img_ids)],
+                       max_new_tokens=meta["MAX_NEW"], output_hidden_states=True, return_dict_in_generate=True)
+    gen = out.sequences[0][S:].tolist()
+    assert gen == g[case + ".generate_ids"].tolist()
+    assert len(out.hidden_states) == len(gen) and out.hidden_states[0][-1].shape == (1, S, d["hidden"])
+    last = torch.cat([hs[-1] for hs in out.hidden_states], dim=1)[0, S:]                  # models.py:182-184
+    assert rel(last, g[case + ".hidden"]) < 1e-4

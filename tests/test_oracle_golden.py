@@ -199,3 +199,26 @@ def test_full_dimension_resamplers_vit_ends_xlv2_fp32():
     ctx, pooled = O.resampler_xlv2_forward(wd, x, depth=c["depth"], heads=c["heads"], dim_head=c["dim_head"])
     assert rel(_rows(ctx, r["row_stride"]), g["xlv2_ctx_f32.rows"]) < 2e-6
     assert rel(pooled, g["xlv2_pooled_f32.rows"]) < 2e-6
+
+
+def test_greedy_loop_pinned_on_hf_generate():
+    """The oracle's greedy loop == a REAL ``GenerationMixin.generate`` run (installed transformers 5.15; the reference pins
+    4.34 — gap stated in oracle/make_golden_greedy.py) with the reference's real logits processor: ids incl. the 65
+    processor-forced tokens and the free tail, EOS stop, last-layer hidden rows."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = load_file(os.path.join(root, "greedy_hf.safetensors"))
+    with open(os.path.join(root, "greedy_hf.json")) as f:
+        meta = json.load(f)
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    img_ids = list(range(meta["IMG_IDS"][0], meta["IMG_IDS"][1] + 1))
+    for tag, eos in (("free", 2), ("eos", meta["eos_case_id"])):
+        gen, hid, _, _ = O.greedy_generate(wd, dims, g["input_ids"], g["inputs_embeds"].clone(), img_ids, meta["MAX_NEW"],
+                                           eos_id=eos)
+        assert gen == g[tag + ".generate_ids"].tolist()
+        assert rel(hid, g[tag + ".hidden"]) < 2e-6
+    assert g["eos.generate_ids"].tolist()[-1] == meta["eos_case_id"] and len(g["eos.generate_ids"]) < meta["MAX_NEW"]

@@ -123,3 +123,60 @@ def test_synthetic_tokenizer_round_trip():
     assert t.encode(s) == ids
     assert t.encode("hello world" + BOI_TOKEN)[-1] == t.img[0] and len(t.encode("hello world")) == 2
     assert t.encode("hello") == t.encode("hello")
+
+
+# ---- pin against the INSTALLED transformers (5.15; the reference pins 4.34 — gap stated below) ---------------------------
+
+@pytest.fixture(scope="module")
+def llama_like(tmp_path_factory):
+    """A sentencepiece model with LLaMA's normaliser settings (identity rule, add_dummy_prefix, NO whitespace removal,
+    byte fallback, split digits), the 66 added image tokens, and both tokenizers on it."""
+    import json
+    import sentencepiece as spm
+    transformers = pytest.importorskip("transformers")
+    d = tmp_path_factory.mktemp("tokpin")
+    open(d / "corpus.txt", "w").write("\n".join((CORPUS + ["[INST] Generate the next scene. [/INST]"]) * 40))
+    spm.SentencePieceTrainer.train(input=str(d / "corpus.txt"), model_prefix=str(d / "tokenizer"), vocab_size=400,
+                                   model_type="bpe", bos_id=1, eos_id=2, unk_id=0, pad_id=-1, byte_fallback=True,
+                                   character_coverage=1.0, add_dummy_prefix=True, normalization_rule_name="identity",
+                                   remove_extra_whitespaces=False, split_digits=True, minloglevel=2)
+    hf = transformers.LlamaTokenizer.from_pretrained(str(d), legacy=True)
+    n0 = len(hf)
+    assert hf.add_tokens(image_token_strings(), special_tokens=False) == 66
+    json.dump({t: n0 + i for i, t in enumerate(image_token_strings())}, open(d / "added_tokens.json", "w"))
+    return hf, LlamaTokenizer.from_pretrained(str(d)), transformers.__version__
+
+
+def test_tokenizer_pinned_on_installed_transformers(llama_like):
+    """``seedstory.tokenizer`` vs ``transformers.LlamaTokenizer`` (legacy=True) on the SAME sentencepiece model + added
+    tokens, for the strings the drivers really encode (gen_george.py:168-176,231-239: question + image tokens, then
+    ``prompt + text + image_tokens`` with ``text`` regex-scrubbed and stripped, then the window cut).
+
+    Version gap, stated: the reference pins transformers 4.34 whose LlamaTokenizer is the *slow* sentencepiece class; the
+    installed 5.15 converts the same model to a `tokenizers` pipeline.  They agree — and this test pins — every id of the
+    driver-shaped strings.  They differ in two places, asserted below as the literal 4.34-slow behaviour the product
+    follows: (a) a text segment that STARTS WITH A SPACE (``</img> y``): 4.34-slow hands the segment to sentencepiece,
+    whose dummy prefix makes it ``▁ ▁y``; 5.15 emits ``▁y``;  (b) ``decode``: 4.34-slow joins added tokens and text runs
+    with single spaces (``spaces_between_special_tokens=True``), 5.15 does not."""
+    hf, mine, ver = llama_like
+    img = "".join(image_token_strings())
+    q = "George the monkey looked at the man with the yellow hat."
+    t1, t2 = "The man smiled and opened the door.", "They walked to the city zoo!"
+    prompts = [q + img, q + img + t1 + img, q + img + t1 + img + t2 + img, "[INST] What happens next? [/INST]" + img,
+               (q + img + t1 + img)[len(q + img) + len("[INST]"):],          # the window cut of gen_george.py:236-237
+               "George", "What happens next in the story?", img, "<img>", "</img>", "a\nb", "x</img>y", "Ünï ☃ 12345"]
+    for p in prompts:
+        a, b = hf.encode(p, add_special_tokens=False), mine.encode(p, add_special_tokens=False)
+        assert a == b, (ver, p[:40], a[:12], b[:12])
+    assert hf.bos_token_id == mine.bos_token_id == 1 and hf.eos_token_id == mine.eos_token_id == 2
+    assert hf.encode("<img>", add_special_tokens=False) == mine.encode("<img>", add_special_tokens=False) == [len(hf) - 66]
+    assert hf.encode(img, add_special_tokens=False) == list(range(len(hf) - 66, len(hf)))
+    # (a) leading-space segment: 4.34-slow semantics (sentencepiece per segment, dummy prefix kept)
+    sp = mine.sp_model
+    assert mine.encode("</img> y", add_special_tokens=False) == [len(hf) - 1] + sp.EncodeAsIds(" y")
+    assert sp.EncodeAsIds(" y")[0] == sp.PieceToId("▁") and len(sp.EncodeAsIds(" y")) == len(sp.EncodeAsIds("y")) + 1
+    # (b) decode spacing of 4.34-slow; the drivers scrub it with re.sub(r'\s*<[^>]*>\s*', ' ', .) (gen_george.py:196)
+    ids = mine.encode("He ran.<img><img_00001></img>ok", add_special_tokens=False)
+    assert mine.decode(ids) == "He ran. <img> <img_00001> </img> ok"
+    import re
+    assert re.sub(r"\s*<[^>]*>\s*", " ", mine.decode(ids)).strip() == re.sub(r"\s*<[^>]*>\s*", " ", hf.decode(ids)).strip()
