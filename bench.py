@@ -128,6 +128,7 @@ def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
     stories' context (ids, image features) and returns img_gen_feat [S,256,4096]."""
     from seedstory import ops
     dev = sts[0].device
+    embs = [None] * eng.n_seq
     for b, st in enumerate(sts):
         eng.select(b)
         if st.step == 0:
@@ -142,10 +143,14 @@ def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
         if kv_reuse and st.step > 0 and not st.evicted_last:
             keep = S - 65                                                 # ... caption + <img> stay cached
             eng.set_lengths(keep, keep)
-            eng.prefill(emb[keep:])
+            embs[b] = emb[keep:]
         else:
             eng.reset()
-            eng.prefill(emb)
+            embs[b] = emb
+    if len(sts) == 1:
+        eng.select(0).prefill(embs[0])
+    else:       # the prompts of the lock-step stories as ONE stacked prefill: layer weights streamed once per round
+        eng.prefill_batch(embs)
     forced = [st.forced() for st in sts]
     e = CAPTION + 65                                                      # index of </img> in the generated ids
     if eng.img_block_enabled():
@@ -320,7 +325,7 @@ def build_engine(device, dtype, n_seq, shared=None):
         shared = dict(layers=[(rnd(3 * H, H), rnd(H, H), rnd(2 * INTER, H), rnd(H, INTER), ones(H), ones(H)) for _ in range(NL)],
                       embed=rnd(VOCAB, H), lm_head=rnd(VOCAB, H), final_norm=ones(H))
     eng = LlamaEngine.from_prebuilt(hidden=H, n_heads=NH, n_layers=NL, inter=INTER, vocab=VOCAB, dtype=dtype, device=device,
-                                    cache_cap=1152, max_new=128, max_prefill_rows=1024, img_ids=IMG_IDS, eos_id=EOS,
+                                    cache_cap=1152, max_new=128, max_prefill_rows=1024 * n_seq, img_ids=IMG_IDS, eos_id=EOS,
                                     n_seq=n_seq, **shared)
     return eng, shared
 
@@ -467,9 +472,20 @@ def main():
     # by 114 rows per story step (prefill GEMM M buckets of 128), and one round touches every other shape (ViT,
     # resamplers, UNet, VAE).  Shapes already in the shipped table cost nothing here.
     for i in range(STORY_LEN):
-        eng.select(0).reset()
-        eng.prefill(torch.zeros(65 if (args.kv_reuse and 0 < i < WINDOW) else prompt_len(i), H, device=device, dtype=dtype))
-    eng.select(0).reset()
+        rows = 65 if (args.kv_reuse and 0 < i < WINDOW) else prompt_len(i)
+        for b in range(SPG):
+            eng.select(b).reset()
+        if SPG == 1:
+            eng.prefill(torch.zeros(rows, H, device=device, dtype=dtype))
+        else:                                   # the stacked prefill of the lock-step stories: M = SPG x rows
+            eng.prefill_batch([torch.zeros(rows, H, device=device, dtype=dtype)] * SPG)
+    if SPG > 1:
+        for b in range(SPG):
+            eng.select(b).reset()
+        eng.prefill_batch([torch.zeros(66, H, device=device, dtype=dtype)] * SPG)      # the image-token block (SPG x 66 rows)
+    for b in range(SPG):
+        eng.select(b).reset()
+    eng.select(0)
     runner.one_step()
     runner.sts = None
     runner.warm(args.warmup)

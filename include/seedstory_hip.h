@@ -66,8 +66,23 @@ int ss_get_tuning(const char* key, int dflt);
  * into the weight): same order of magnitude, covered by the bf16 parity gates.
  *   ss_rowstats     x [M, K] (16-bit, row stride ld, K <= 2048) -> rstd_out[M], shift_out[M] (fp32)
  *   ss_gemm_lnfold  A [M, K] raw rows, Wg [N, K]; `bias` carries d (model dtype); K % 64 == 0, N % 16 == 0;
- *                   epilogue flags BIAS | GELU | GEGLU_PAIR. */
+ *                   epilogue flags BIAS | GELU | GEGLU_PAIR.
+ *
+ * Producer-carried statistics (round 3): the LayerNorm's row statistics need no pass of their own when the GEMM that
+ * PRODUCES h (attn.to_out + residual, ff.net.2 + residual, proj_in) accumulates them while it stores h:
+ *   ss_gemm_rowstat      ss_gemm whose epilogue also adds, per output row m, sum_n C[m][n] and sum_n C[m][n]^2 of the
+ *                        values as stored (rounded to the model dtype, residual included) into rowstat_accum[2m],
+ *                        rowstat_accum[2m+1] (fp64 atomics — one pair per row per column tile; the caller zeroes the
+ *                        array before the call; 16-byte aligned; any epilogue except GEGLU_PAIR);
+ *   ss_rowstat_finalize  rowstat[2m .. 2m+1] -> rstd_out[m], shift_out[m] (mean = s / width, var = q / width - mean^2
+ *                        formed in fp64: no cancellation), the inputs of ss_gemm_lnfold; re-zeroes rowstat for the next
+ *                        producer.  One accumulator per row count serves a whole forward: producer, finalize and
+ *                        consumer follow each other on the stream. */
 int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream);
+int ss_gemm_rowstat(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                    int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, double* rowstat_accum,
+                    int dtype, void* stream);
+int ss_rowstat_finalize(double* rowstat, int64_t M, int64_t width, float eps, float* rstd_out, float* shift_out, void* stream);
 int ss_gemm_lnfold(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
                    const float* shift, const float* colsum, const void* bias, int epilogue, int dtype, void* stream);
 
@@ -328,6 +343,13 @@ int ss_llama_kv_gather(ss_llama* h, const int32_t* keep_idx_dev, int64_t n_keep,
  * but only row -1 is consumed by greedy search).  Advances kv_len/pos by M. */
 int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* pos_ids, void* hidden_out,
                      void* stream);
+/* ss_llama_prefill for several sequence slots in ONE sweep of the weights: embeds = the slots' new rows stacked
+ * slot-major [sum(host_rows), hidden], host_rows[n_seq] (host array; 0 = slot sits out).  Every projection runs once on
+ * the stack (the layer weights are streamed once per call, not once per slot); RoPE / KV append / bottom-right causal
+ * attention run per slot against that slot's cache, positions continue from each slot's own `pos`.  Each slot's last
+ * row's logits land in that slot's logits buffer; hidden_out [sum(host_rows), hidden] or NULL.  Used for the image-token
+ * block continuation of lock-step stories (generation.py:19-31 forces those ids) and their prompt prefill. */
+int ss_llama_prefill_batch(ss_llama* h, const void* embeds, const int64_t* host_rows, void* hidden_out, void* stream);
 
 /* Greedy decode (HF greedy search as driven from models.py:146-153):
  * starting from the logits buffer left by prefill, runs up to n_steps iterations of

@@ -556,7 +556,8 @@ static void conv_geometry(GemmArgs& g, int64_t B, int64_t H, int64_t Wd, int64_t
 
 template <typename T>
 int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, hipStream_t s) {
+                int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, hipStream_t s,
+                double* rowstat_out = nullptr) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(K % V == 0 && lda % V == 0 && ldw % V == 0, "gemm: K/lda/ldw must be multiples of %d (K=%lld)", V,
                (long long)K);
@@ -572,6 +573,27 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
     g.swz = tuning_get("gemm_xcd_swizzle", 8);
+    if (rowstat_out) {
+        // statistics epilogue: only the staged software-pipelined tiles 61..72 have it (ids + 200); 256x256 tiles (60 / 69)
+        // and non-staged choices fall to the 160- / 128-wide staged tile of the shape
+        if constexpr (Tr<T>::kVec != 8) {
+            set_error("ss_gemm_rowstat: 16-bit dtypes only");
+            return SS_EINVAL;
+        } else {
+            SS_REQUIRE(K % 64 == 0 && N % 8 == 0 && M > 128, "ss_gemm_rowstat: needs K %% 64 == 0, N %% 8 == 0, M > 128 (M=%lld N=%lld K=%lld)",
+                       (long long)M, (long long)N, (long long)K);
+            g.rowstat_out = rowstat_out;
+            int cfg = lookup_cfg<T>(g);
+            const bool has = cfg == 61 || cfg == 62 || cfg == 63 || cfg == 64 || cfg == 65 || cfg == 67 || cfg == 71 || cfg == 72;
+            if (!has) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : 65;
+            const int rc = gemm_sp_dispatch<T>(cfg + 200, g, s);
+            if (rc == 1) {
+                set_error("ss_gemm_rowstat: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 200, (long long)M, (long long)N, (long long)K);
+                return SS_EINVAL;
+            }
+            return rc;
+        }
+    }
     return gemm_dispatch_cfg<T>(lookup_cfg<T>(g), g, s);
 }
 
@@ -683,6 +705,22 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ x, 
     if (lane == 0) { rstd[row] = r; shift[row] = -mean * r; }
 }
 
+// (sum, sum of squares) accumulated by a producer GEMM (RSTAT epilogue) -> the folded LayerNorm's row vectors; the
+// accumulator is re-zeroed for its next producer.  mean / variance in fp64: E[x^2] - mean^2 does not cancel there.
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(double* __restrict__ stat, int rows, double inv_width, float eps,
+                                                               float* __restrict__ rstd, float* __restrict__ shift) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    double2* p = reinterpret_cast<double2*>(stat) + m;
+    const double2 st = *p;
+    *p = make_double2(0.0, 0.0);
+    const double mean = st.x * inv_width;
+    const double var = fmax(st.y * inv_width - mean * mean, 0.0);
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[m] = r;
+    shift[m] = -(float)mean * r;
+}
+
 template <typename T>
 int rowstats_launch(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd, float* shift, hipStream_t s) {
     if constexpr (Tr<T>::kVec != 8) {
@@ -717,6 +755,23 @@ int ss_gemm(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t
             int64_t ldw, int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue,
             int dtype, void* stream) {
     return ss::gemm_dev(A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue, dtype, (hipStream_t)stream);
+}
+
+int ss_gemm_rowstat(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                    int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, double* rowstat_accum,
+                    int dtype, void* stream) {
+    SS_REQUIRE(rowstat_accum && (((size_t)rowstat_accum) & 15) == 0, "ss_gemm_rowstat: rowstat_accum missing or not 16-byte aligned");
+    SS_REQUIRE(!(epilogue & SS_EPI_GEGLU_PAIR), "ss_gemm_rowstat: not defined for the GEGLU epilogue");
+    return SS_DISPATCH(dtype, ss::gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue,
+                       (hipStream_t)stream, rowstat_accum);
+}
+
+int ss_rowstat_finalize(double* rowstat, int64_t M, int64_t width, float eps, float* rstd_out, float* shift_out, void* stream) {
+    SS_REQUIRE(rowstat && rstd_out && shift_out && M > 0 && width > 0 && (((size_t)rowstat) & 15) == 0, "ss_rowstat_finalize: bad arguments");
+    hipLaunchKernelGGL(ss::rowstat_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowstat,
+                       (int)M, 1.0 / (double)width, eps, rstd_out, shift_out);
+    SS_LAUNCH_CHECK("rowstat_finalize");
+    return SS_OK;
 }
 
 int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream) {

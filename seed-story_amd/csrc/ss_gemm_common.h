@@ -118,6 +118,11 @@ struct GemmArgs {
     const float* scale_a = nullptr; const float* scale_w = nullptr;
     // folded LayerNorm (16-bit operands): scale_a = rstd[m], shift_a = -mean[m] * rstd[m], scale_w = c[n] (see EM below)
     const float* shift_a = nullptr;
+    // row statistics for the folded LayerNorm of the CONSUMER, accumulated by the PRODUCER of the tensor (kernels
+    // instantiated with RSTAT): the epilogue adds  sum_n out[m][n]  and  sum_n out[m][n]^2  of the values it stores
+    // (rounded to T, residual included) into rowstat_out[2m], rowstat_out[2m+1] — fp64 atomics, one pair per row per
+    // column strip of a wave; ss_rowstat_finalize turns them into (rstd, shift) and re-zeroes the array.
+    double* rowstat_out = nullptr;
 };
 
 // Linear workgroup id -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and
@@ -207,7 +212,7 @@ __device__ __forceinline__ void ld4(const T* p, float (&v)[4]) {
 // EM (epilogue scaling mode): 0 none | 1 fp8 de-quantisation  t = acc * scale_a[m] * scale_w[n]  | 2 folded LayerNorm
 //   t = acc * scale_a[m] + shift_a[m] * scale_w[n]   (scale_a = rstd, shift_a = -mean * rstd, scale_w = column sums of the
 //   gamma-scaled weight; beta's contribution rides in the bias) — see ss_gemm_lnfold
-template <typename T, int FM, int FN, int EM = 0>
+template <typename T, int FM, int FN, int EM = 0, bool RSTAT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                               int l15, int grp) {
     const int M = g.M, N = g.N;
@@ -275,6 +280,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                         if (n0 + r < N) v[r] += Tr<T>::ld(res + (int64_t)m * g.ldr + n0 + r);
                 }
             }
+            if constexpr (RSTAT) {   // statistics of the values as stored; the 4 lane groups of a row fold into group 0.
+                // (rows beyond M took `continue` above: their lanes sit out the shuffle, which only pairs lanes of ONE row)
+                if (g.rowstat_out) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < N) { const float o = Tr<T>::rnd(v[r]); a += o; b = fmaf(o, o, b); }
+                    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+                    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+                    if (grp == 0) {
+                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m, (double)a);
+                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m + 1, (double)b);
+                    }
+                }
+            }
             if (g.epi & SS_EPI_GEGLU_PAIR) {   // (value, gate) interleaved columns -> out[m][n/2] = value * gelu(gate)
                 const float o0 = v[0] * Tr<T>::rnd(gelu_for<T>(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_for<T>(v[3]));
                 if (full && ((g.ldc & 1) == 0) && (((size_t)g.C & 3) == 0) && Tr<T>::kVec == 8) {
@@ -309,7 +329,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 // before staging (value rounded to T exactly where the direct path rounds it), the residual is added on the coalesced
 // read-back.  Requirements (checked by the caller): the wave's TM x TN sub-tile lies inside [M, N) in N (rows are
 // masked), C / residual 16-byte aligned with ldc / ldr % 8 == 0.
-template <typename T, int FM, int FN, int CR, int EM = 0>
+template <typename T, int FM, int FN, int CR, int EM = 0, bool RSTAT = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                      int lane, char* stg) {
     static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
@@ -395,6 +415,31 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                         u = pack<T>(a);
                     }
                     *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n_out0 + c16 * 8) = u;
+                    if constexpr (RSTAT) {
+                        if (g.rowstat_out) {   // (sum, sum of squares) of the 8 stored values, parked in the piece just consumed
+                            float a[8];
+                            unpack<T>(u, a);
+                            float sv = 0.f, qv = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { sv += a[e]; qv = fmaf(a[e], a[e], qv); }
+                            *reinterpret_cast<float2*>(stg + row * RS + c16 * 16) = make_float2(sv, qv);
+                        }
+                    }
+                }
+            }
+            if constexpr (RSTAT) {
+                if (g.rowstat_out) {   // one wave's LDS operations execute in order: lane r < CR folds row r's LPR partials
+                    const int m = m_base + c * CR + lane;
+                    if (lane < CR && m < M) {
+                        float sv = 0.f, qv = 0.f;
+#pragma unroll
+                        for (int q = 0; q < LPR; ++q) {
+                            const float2 t = *reinterpret_cast<const float2*>(stg + lane * RS + q * 16);
+                            sv += t.x; qv += t.y;
+                        }
+                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m, (double)sv);
+                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m + 1, (double)qv);
+                    }
                 }
             }
         };

@@ -562,6 +562,83 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
     return ss_llama_set_lengths(h, kv1, new_pos, stream);
 }
 
+// The same forward for SEVERAL sequence slots in one sweep of the weights: the rows of all participating slots are
+// stacked (slot-major) and every projection runs ONCE on the stack (M = sum of the slots' rows: the 13.2 GB of layer
+// weights are streamed once per call instead of once per slot, and the GEMMs see 4x the rows); RoPE / KV append and the
+// bottom-right causal attention stay per slot (each slot's rows against its own cache).  Used for the image-token block
+// continuation of lock-step stories (4 x 66 rows) and for their prompt prefill (4 x S rows).
+int ss_llama_prefill_batch(ss_llama* h, const void* embeds, const int64_t* host_rows, void* hidden_out, void* stream) {
+    SS_REQUIRE(h && embeds && host_rows, "llama_prefill_batch: bad arguments");
+    const ss_llama_config& g = h->cfg;
+    int64_t M = 0;
+    for (int b = 0; b < h->n_seq; ++b) {
+        const int64_t r = host_rows[b];
+        SS_REQUIRE(r >= 0, "llama_prefill_batch: negative row count for slot %d", b);
+        SS_REQUIRE(h->kv_len[b] + r <= g.cache_cap, "llama_prefill_batch: KV cache overflow in slot %d (%lld + %lld > %d)", b,
+                   (long long)h->kv_len[b], (long long)r, g.cache_cap);
+        SS_REQUIRE(h->pos[b] + r <= g.max_pos, "llama_prefill_batch: position overflow in slot %d", b);
+        M += r;
+    }
+    SS_REQUIRE(M > 0 && M <= h->max_rows, "llama_prefill_batch: %lld stacked rows (max_prefill_rows=%lld)", (long long)M,
+               (long long)h->max_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = g.dtype;
+    const int64_t H = g.hidden, I = g.inter;
+    const int hd = h->hd;
+    const size_t e = h->esz;
+    const size_t plane = (size_t)g.n_heads * g.cache_cap * hd * e;
+    int rc;
+    SS_HIP(hipMemcpyAsync(h->x, embeds, (size_t)M * H * e, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < g.n_layers; ++l) {
+        const ss_llama_layer_weights& L = h->layers[l];
+        if ((rc = rmsnorm_rows(h->x, L.ln1, h->xn, M, H, g.rms_eps, dt, s))) return rc;
+        if ((rc = gemm_dev(h->xn, L.wqkv, h->qkv, M, 3 * H, H, H, H, 3 * H, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
+            return rc;
+        int64_t r0 = 0;
+        for (int b = 0; b < h->n_seq; ++b) {
+            const int64_t r = host_rows[b];
+            if (!r) continue;
+            char* kc = h->kc + (size_t)b * h->seq_kv_bytes() + (size_t)l * plane;
+            char* vc = h->vc + (size_t)b * h->seq_kv_bytes() + (size_t)l * plane;
+            const int64_t kv0 = h->kv_len[b], kv1 = kv0 + r;
+            char* qkv_b = h->qkv + (size_t)r0 * 3 * H * e;
+            char* q_b = h->q + (size_t)r0 * H * e;
+            if ((rc = ss_rope_kv_append(qkv_b, q_b, kc, vc, h->w.rope_cos, h->w.rope_sin, nullptr, h->pos[b], r, g.n_heads,
+                                        hd, kv0, g.cache_cap, dt, stream)))
+                return rc;
+            if ((rc = ss_attention(q_b, kc, vc, h->attn + (size_t)r0 * H * e, 1, g.n_heads, r, kv1, hd, 0, hd, H, 0,
+                                   (int64_t)g.cache_cap * hd, hd, 0, (int64_t)g.cache_cap * hd, hd, 0, hd, H,
+                                   1.0f / sqrtf((float)hd), 1, dt, stream)))
+                return rc;
+            r0 += r;
+        }
+        if ((rc = gemm_dev(h->attn, L.wo, h->x, M, H, H, H, H, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+        if ((rc = rmsnorm_rows(h->x, L.ln2, h->xn, M, H, g.rms_eps, dt, s))) return rc;
+        if ((rc = gemm_dev(h->xn, L.wgu, h->gu, M, 2 * I, H, H, H, 2 * I, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
+            return rc;
+        if ((rc = ss_silu_mul(h->gu, h->hm, M, I, dt, stream))) return rc;
+        if ((rc = gemm_dev(h->hm, L.wdown, h->x, M, H, I, I, I, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+    }
+    void* hid = hidden_out ? hidden_out : (void*)h->xn;
+    if ((rc = rmsnorm_rows(h->x, h->w.final_norm, hid, M, H, g.rms_eps, dt, s))) return rc;
+    const int keep_cur = h->cur;
+    int64_t r0 = 0;
+    for (int b = 0; b < h->n_seq; ++b) {
+        const int64_t r = host_rows[b];
+        if (!r) continue;
+        const char* last = (const char*)hid + (size_t)(r0 + r - 1) * H * e;
+        char* logits = h->logits + (size_t)b * g.vocab * e;
+        if ((rc = gemv_dev(h->w.lm_head, last, logits, g.vocab, H, nullptr, 0.f, nullptr, nullptr, SS_EPI_NONE, nullptr, dt, s)))
+            return rc;
+        h->cur = b;
+        rc = ss_llama_set_lengths(h, h->kv_len[b] + r, h->pos[b] + r, stream);
+        h->cur = keep_cur;
+        if (rc) return rc;
+        r0 += r;
+    }
+    return SS_OK;
+}
+
 // stage one slot's initial decode state in the pinned upload area; returns the launch bound
 static int64_t stage_seq(ss_llama* h, int b, int64_t n_steps, int32_t last_id, const int32_t* forced, int64_t n_forced,
                          bool active) {

@@ -60,6 +60,8 @@ PROTOTYPES = {
     "ss_device_info": (C.c_int, [i32p]),
     "ss_rowstats": (C.c_int, [vp, i64, i64, i64, f32, vp, vp, C.c_int, vp]),
     "ss_gemm_lnfold": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ss_gemm_rowstat": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
+    "ss_rowstat_finalize": (C.c_int, [vp, i64, i64, f32, vp, vp, vp]),
     "ss_quantize_rows_fp8": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, f32, C.c_int, vp]),
     "ss_gemm_fp8": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp]),
     "ss_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
@@ -108,6 +110,7 @@ PROTOTYPES = {
     "ss_llama_get_lengths": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "ss_llama_kv_gather": (C.c_int, [vp, vp, i64, vp]),
     "ss_llama_prefill": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "ss_llama_prefill_batch": (C.c_int, [vp, vp, C.POINTER(i64), vp, vp]),
     "ss_llama_generate": (C.c_int, [vp, i64, i32, i32p, i64, C.POINTER(i64), vp]),
     "ss_llama_generate_batch": (C.c_int, [vp, i64, i32p, i32p, i64, C.POINTER(i64), i32p, C.POINTER(i64), vp]),
     "ss_llama_profile_decode": (C.c_int, [vp, i64, C.POINTER(f32), C.POINTER(C.c_double), vp]),

@@ -333,9 +333,12 @@ class UNet2DConditionModel(nn.Module):
 
     def enable_lnfold(self, on=True):
         """Fold norm1 / norm2 / norm3 of every transformer block into the GEMM that follows (q|k|v, to_q, GEGLU ff1):
-        the GEMM streams the raw rows, the epilogue applies the per-row statistics (`ss_rowstats` + `ss_gemm_lnfold`);
-        the three LayerNorm launches and their normalised tensors disappear.  bf16 path only (fp8 fuses the LayerNorm into
-        its quantiser instead)."""
+        the GEMM streams the raw rows and its epilogue applies the per-row statistics (`ss_gemm_lnfold`); the statistics
+        are accumulated by the epilogue of the GEMM that PRODUCED the rows (`ss_gemm_rowstat` + `ss_rowstat_finalize`), so
+        the three LayerNorm launches, their normalised tensors and every statistics pass disappear.  16-bit path only (fp8
+        fuses the LayerNorm into its quantiser instead; fp32 runs the plain LayerNorm).  OFF by default: measured on MI355X
+        (profiles/round3_lnfold_rowstat_ab.txt) the forward is 66.4 ms either way — the 3.2 ms of LayerNorm launches are
+        traded for 0.9 ms of ss_rowstat_finalize launches and a ~4 % slower folded epilogue on the q|k|v / ff1 GEMMs."""
         if bool(on) != getattr(self, "_lnfold", False):
             self._lnfold = bool(on)
             self._prep = None
@@ -369,35 +372,68 @@ class UNet2DConditionModel(nn.Module):
                            "proj_in.weight", "proj_out.weight")) and v.shape[1] % 128 == 0:
                 P[k + ".fp8"] = ops.quantize_rows_fp8(v.contiguous())
 
-    def _lin(self, P, name, x, *, ln=None, bias=None, residual=None, geglu=False):
-        """One linear layer of a transformer block: fp8 when enabled and prepared for this weight, else bf16."""
+    def _lin(self, P, name, x, *, ln=None, bias=None, residual=None, geglu=False, rowstat=None):
+        """One linear layer of a transformer block: fp8 when enabled and prepared for this weight, else bf16.
+        ``rowstat``: fp64 [M, 2] accumulator for the row statistics of the OUTPUT (see `_lin_ln`)."""
         f8 = P.get(name + ".fp8") if getattr(self, "_fp8", False) else None
         if f8 is None:
             if ln is not None:
                 x = ops.layernorm(x, ln[0], ln[1], ln[2])
             if geglu:
                 return ops.gemm_geglu(x, P[name], bias)
-            return ops.gemm(x, P[name], bias=bias, residual=residual)
+            return ops.gemm(x, P[name], bias=bias, residual=residual, rowstat=rowstat)
+        assert rowstat is None
         x8, sx = ops.quantize_rows_fp8(x, ln=ln)
         return ops.gemm_fp8(x8, sx, f8[0], f8[1], bias=bias, residual=residual, geglu=geglu)
 
-    def _lin_ln(self, P, name, x, ln, bias=None, geglu=False):
-        """LayerNorm + linear: folded (ss_gemm_lnfold) when enabled and prepared for this weight."""
-        lnf = P.get(name + ".lnf") if getattr(self, "_lnfold", False) and not getattr(self, "_fp8", False) else None
+    def _lnfold_on(self):
+        return getattr(self, "_lnfold", False) and not getattr(self, "_fp8", False)
+
+    def _lin_ln(self, P, name, x, ln, bias=None, geglu=False, rowstat=None):
+        """LayerNorm + linear: folded (ss_gemm_lnfold) when enabled and prepared for this weight.  The row statistics
+        come from ``rowstat`` when the GEMM that produced x accumulated them in its epilogue (ss_gemm_rowstat ->
+        ss_rowstat_finalize: no pass over x at all), else from a statistics pass over x (ss_rowstats)."""
+        lnf = P.get(name + ".lnf") if self._lnfold_on() else None
         if lnf is None:
+            assert rowstat is None
             return self._lin(P, name, x, ln=ln, bias=bias, geglu=geglu)
-        rstd, shift = ops.rowstats(x, ln[2])
+        if rowstat is not None:
+            rstd, shift = ops.rowstat_finalize(rowstat, x.shape[1], ln[2], out=self._rs_vec(x.shape[0], x.device))
+        else:
+            rstd, shift = ops.rowstats(x, ln[2])
         return ops.gemm_lnfold(x, lnf[0], rstd, shift, lnf[1], bias_d=lnf[2], geglu=geglu)
+
+    def _rs_acc(self, rows, device):
+        """fp64 [rows, 2] accumulator of producer-side row statistics: all zeros between uses (ss_rowstat_finalize re-zeroes
+        what it reads; `forward` zeroes it once more at its start in case a previous forward was interrupted)."""
+        bufs = self.__dict__.setdefault("_rs_bufs", {})
+        b = bufs.get((rows, str(device)))
+        if b is None:
+            b = bufs[(rows, str(device))] = (torch.zeros(rows, 2, dtype=torch.float64, device=device),
+                                             torch.empty(2, rows, dtype=torch.float32, device=device))
+            self._kv_gen = getattr(self, "_kv_gen", 0) + 1      # a captured forward does not know this buffer
+        return b[0]
+
+    def _rs_vec(self, rows, device):
+        self._rs_acc(rows, device)
+        return self._rs_bufs[(rows, str(device))][1]
 
     def _transformer(self, P, n, x, B, HW, ctx2d, Lctx, heads, layers, groups):
         h = ops.groupnorm(x, P[n + ".norm.weight"], P[n + ".norm.bias"], B, groups, 1e-6, silu=False)
-        h = self._lin(P, n + ".proj_in.weight", h, bias=P[n + ".proj_in.bias"])
+        # producer-carried LayerNorm statistics: every GEMM that writes h (proj_in, attn1/attn2 to_out, ff.net.2)
+        # accumulates the row sums the NEXT norm needs while it stores h; requires the folded form of all three norms
+        rs = None
+        if self._lnfold_on() and h.shape[0] > 128 and all(
+                (n + ".transformer_blocks.%d%s.lnf" % (k, w)) in P for k in range(layers)
+                for w in (".attn1.qkv", ".attn2.to_q.weight", ".ff.net.0.proj.pairs.weight")):
+            rs = self._rs_acc(h.shape[0], h.device)
+        h = self._lin(P, n + ".proj_in.weight", h, bias=P[n + ".proj_in.bias"], rowstat=rs)
         for k in range(layers):
             b = n + ".transformer_blocks.%d" % k
-            qkv = self._lin_ln(P, b + ".attn1.qkv", h, (P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5))
+            qkv = self._lin_ln(P, b + ".attn1.qkv", h, (P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-5), rowstat=rs)
             a = ops.attention_qkv_packed(qkv, B, HW, heads)
-            h = self._lin(P, b + ".attn1.to_out.0.weight", a, bias=P[b + ".attn1.to_out.0.bias"], residual=h)
-            q = self._lin_ln(P, b + ".attn2.to_q.weight", h, (P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5))
+            h = self._lin(P, b + ".attn1.to_out.0.weight", a, bias=P[b + ".attn1.to_out.0.bias"], residual=h, rowstat=rs)
+            q = self._lin_ln(P, b + ".attn2.to_q.weight", h, (P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-5), rowstat=rs)
             kv = self._ctx_kv.get(b)
             if kv is None:   # K/V of the 64 context tokens do not depend on the denoising step: once per image,
                 # written into a per-block buffer that keeps its address (a captured forward reads it on replay)
@@ -410,10 +446,11 @@ class UNet2DConditionModel(nn.Module):
                     self._kv_gen = getattr(self, "_kv_gen", 0) + 1      # a captured forward holding the old address is stale
                 kv = self._ctx_kv[b] = ops.gemm(ctx2d, w, out=buf)
             a = ops.attention_q_kvpacked(q, kv, B, HW, Lctx, heads)
-            h = self._lin(P, b + ".attn2.to_out.0.weight", a, bias=P[b + ".attn2.to_out.0.bias"], residual=h)
+            h = self._lin(P, b + ".attn2.to_out.0.weight", a, bias=P[b + ".attn2.to_out.0.bias"], residual=h, rowstat=rs)
             u = self._lin_ln(P, b + ".ff.net.0.proj.pairs.weight", h, (P[b + ".norm3.weight"], P[b + ".norm3.bias"], 1e-5),
-                             bias=P[b + ".ff.net.0.proj.pairs.bias"], geglu=True)
-            h = self._lin(P, b + ".ff.net.2.weight", u, bias=P[b + ".ff.net.2.bias"], residual=h)
+                             bias=P[b + ".ff.net.0.proj.pairs.bias"], geglu=True, rowstat=rs)
+            h = self._lin(P, b + ".ff.net.2.weight", u, bias=P[b + ".ff.net.2.bias"], residual=h,
+                          rowstat=rs if k + 1 < layers else None)      # the last block's output feeds proj_out, not a norm
         return self._lin(P, n + ".proj_out.weight", h, bias=P[n + ".proj_out.bias"], residual=x)
 
     @torch.no_grad()
@@ -424,6 +461,8 @@ class UNet2DConditionModel(nn.Module):
         dt, dev = sample.dtype, sample.device
         B, _, H, W = sample.shape
         boc, G, L = c["block_out_channels"], c["norm_groups"], c["layers_per_block"]
+        for acc, _vec in self.__dict__.get("_rs_bufs", {}).values():
+            acc.zero_()
         # time + added ("text_time") conditioning: sinusoids on the host, MLPs on the device
         temb = kw.get("temb_in")          # [B, 320] device tensor (graph replay: no host->device copy inside the capture)
         if temb is None:

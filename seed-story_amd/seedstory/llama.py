@@ -223,6 +223,44 @@ class LlamaEngine:
               "ss_llama_prefill")
         return hid
 
+    def prefill_batch(self, embeds, want_hidden=False):
+        """``prefill`` for several sequence slots in ONE sweep of the weights (ss_llama_prefill_batch): ``embeds[b]`` =
+        slot b's new rows [M_b, hidden] or None.  Returns the per-slot hidden rows (or None) — each slot's last row's
+        logits land in that slot's logits buffer and its lengths advance by M_b."""
+        S = self.n_seq
+        assert len(embeds) == S
+        rows = [0 if e is None else int(e.shape[0]) for e in embeds]
+        live = [e.to(device=self.device, dtype=self.dtype) for e in embeds if e is not None and e.shape[0]]
+        if not live:
+            return [None] * S
+        M = sum(rows)
+        if M > self.max_rows:                      # engine sized for fewer stacked rows: slot by slot, max_rows at a time
+            out, step, keep = [], int(self.max_rows), self._cur
+            for b, e in enumerate(embeds):
+                if not rows[b]:
+                    out.append(None)
+                    continue
+                self.select(b)
+                parts = [self.prefill(e[i:i + step], want_hidden=want_hidden) for i in range(0, rows[b], step)]
+                out.append(None if not want_hidden else (parts[0] if len(parts) == 1 else torch.cat([p.clone() for p in parts])))
+            self.select(keep)
+            return out
+        stack = live[0].contiguous() if len(live) == 1 else torch.cat(live, dim=0)
+        hid = torch.empty(M, self.hidden, dtype=self.dtype, device=self.device) if want_hidden else None
+        if M > 128:
+            code, Hd, I = ops.dt(self.dtype), self.hidden, self.inter
+            for n, k in ((3 * Hd, Hd), (Hd, Hd), (2 * I, Hd), (Hd, I)):
+                tune.ensure_gemm(M, n, k, code, 0, self.device)
+        arr = (C.c_int64 * S)(*rows)
+        check(lib().ss_llama_prefill_batch(self._h, stack.data_ptr(), arr, ops.p(hid), ops.stream()), "ss_llama_prefill_batch")
+        if not want_hidden:
+            return [None] * S
+        out, r0 = [], 0
+        for b in range(S):
+            out.append(hid[r0:r0 + rows[b]] if rows[b] else None)
+            r0 += rows[b]
+        return out
+
     def generate(self, n_steps, last_prompt_id, forced=None):
         """Greedy decode from the current logits; returns the number of generated tokens."""
         forced = [] if forced is None else [int(t) for t in forced]
@@ -269,14 +307,20 @@ class LlamaEngine:
     def set_stop_id(self, token_id):
         check(lib().ss_llama_set_stop_id(self._h, int(token_id)), "ss_llama_set_stop_id")
 
-    def _img_block(self, remaining, forced):
-        """The slot's decode loop has just produced ``<img>`` (not fed yet).  Feeds the forced block; returns
-        (tokens appended, hidden rows [rows, H], id of the last token fed or None when the block ended the budget)."""
+    def _img_block_plan(self, remaining, forced):
+        """(tokens the block contributes, rows to feed) for a slot whose loop has just produced ``<img>``."""
         blk = self.img_ids
         m = min(remaining, len(blk) - 1)                          # tokens the block contributes: blk[1 .. m]
         if forced[:m] != blk[1:m + 1][:len(forced[:m])]:
             raise _lib.SSError("forced tokens contradict the image-token schedule that follows <img>")
         rows = m + 1 if remaining > len(blk) - 1 else m            # </img> is fed only when generation goes on after it
+        return m, rows
+
+    def _img_block(self, remaining, forced):
+        """The slot's decode loop has just produced ``<img>`` (not fed yet).  Feeds the forced block; returns
+        (tokens appended, hidden rows [rows, H], id of the last token fed or None when the block ended the budget)."""
+        blk = self.img_ids
+        m, rows = self._img_block_plan(remaining, forced)
         ids = torch.tensor(blk[:rows], dtype=torch.int32, device=self.device)
         emb = ops.gather_rows(self.embed, ids)
         step = int(self.max_rows)                                   # rows per prefill call the engine was sized for
@@ -330,9 +374,12 @@ class LlamaEngine:
         rem, last, active = [int(n_steps)] * S, [int(t) for t in last_prompt_ids], [True] * S
         self.set_stop_id(boi)
         try:
+            blk = self.img_ids
             while any(active):
                 n_call = min(rem[b] for b in range(S) if active[b])
                 ns = self.generate_batch(n_call, last, forced, active)
+                feed = [None] * S          # rows every slot feeds after this call: ONE stacked continuation (weights once)
+                plan = {}
                 for b in range(S):
                     if not active[b]:
                         continue
@@ -344,19 +391,32 @@ class LlamaEngine:
                     forced[b], rem[b] = forced[b][n:], rem[b] - n
                     if n == 0 or rem[b] == 0 or g[-1] == self.eos_id:
                         active[b] = False
-                    elif g[-1] == boi:
-                        toks, hb, last_fed = self._img_block(rem[b], forced[b])
-                        ids[b] += toks
-                        hid[b].append(hb)
-                        forced[b], rem[b] = forced[b][len(toks):], rem[b] - len(toks)
-                        if last_fed is None:
-                            active[b] = False
-                        else:
-                            last[b] = last_fed
+                    elif g[-1] == boi:      # the forced image-token block of this slot
+                        m, rows = self._img_block_plan(rem[b], forced[b])
+                        feed[b] = torch.tensor(blk[:rows], dtype=torch.int32, device=self.device)
+                        plan[b] = (m, rows)
                     else:       # stopped by this call's common limit: feed its last token, resume from fresh logits
-                        t = torch.tensor([g[-1]], dtype=torch.int32, device=self.device)
-                        hid[b].append(self.prefill(ops.gather_rows(self.embed, t), want_hidden=True))
-                        last[b] = g[-1]
+                        feed[b] = torch.tensor([g[-1]], dtype=torch.int32, device=self.device)
+                        plan[b] = None
+                if plan:
+                    hbs = self.prefill_batch([None if f is None else ops.gather_rows(self.embed, f) for f in feed],
+                                             want_hidden=True)
+                    if _lib.get_tuning("img_block_logits", 1) and any(v is not None for v in plan.values()):
+                        # the reference's per-position logits of the block rows (unused: those tokens are forced)
+                        ops.gemm(torch.cat([hbs[b] for b, v in plan.items() if v is not None]).contiguous(), self.lm_head)
+                    for b, v in plan.items():
+                        hid[b].append(hbs[b].clone())
+                        if v is None:
+                            last[b] = ids[b][-1]
+                            continue
+                        m, rows = v
+                        toks = blk[1:m + 1]
+                        ids[b] += toks
+                        forced[b], rem[b] = forced[b][len(toks):], rem[b] - len(toks)
+                        if rows == m + 1:
+                            last[b] = blk[rows - 1]
+                        else:
+                            active[b] = False
         finally:
             self.set_stop_id(-1)
         return ids, [torch.cat(h)[:max(len(i) - 1, 0)] for h, i in zip(hid, ids)]

@@ -151,8 +151,9 @@ def attn_decode(q, kcache, vcache, kv_len_dev):
     return out
 
 
-def gemm(a, w, bias=None, residual=None, gelu=False, out=None):
-    """a [M, K] @ w[N, K]^T (+bias)(+gelu)(+residual) -> [M, N]"""
+def gemm(a, w, bias=None, residual=None, gelu=False, out=None, rowstat=None):
+    """a [M, K] @ w[N, K]^T (+bias)(+gelu)(+residual) -> [M, N].  ``rowstat`` (fp64 [M, 2], zeroed by the caller): the
+    epilogue also accumulates (sum, sum of squares) of every stored output row into it (ss_gemm_rowstat)."""
     _req(a); _req(w)
     M, K = a.shape
     N = w.shape[0]
@@ -160,6 +161,11 @@ def gemm(a, w, bias=None, residual=None, gelu=False, out=None):
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RESIDUAL if residual is not None else 0)
     tune.ensure_gemm(M, N, K, dt(a), epi, a.device)
+    if rowstat is not None:
+        assert rowstat.dtype == torch.float64 and rowstat.is_contiguous() and rowstat.numel() == 2 * M
+        check(lib().ss_gemm_rowstat(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, p(rowstat),
+                                    dt(a), stream()), "ss_gemm_rowstat")
+        return out
     check(lib().ss_gemm(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, dt(a), stream()),
           "ss_gemm")
     return out
@@ -198,6 +204,15 @@ def gemm_lnfold(x, wg, rstd, shift, colsum, bias_d=None, gelu=False, geglu=False
     check(lib().ss_gemm_lnfold(p(x), p(wg), p(out), M, N, K, No, p(rstd), p(shift), p(colsum), p(bias_d), epi, dt(x), stream()),
           "ss_gemm_lnfold")
     return out
+
+
+def rowstat_finalize(rowstat, width, eps, out=None):
+    """(sum, sum of squares) accumulated by ``gemm(..., rowstat=)`` -> (rstd [M], -mean * rstd [M]) fp32 for
+    `gemm_lnfold`; ``rowstat`` is re-zeroed for its next producer."""
+    M = rowstat.shape[0]
+    st = torch.empty(2, M, dtype=torch.float32, device=rowstat.device) if out is None else out
+    check(lib().ss_rowstat_finalize(p(rowstat), M, int(width), float(eps), p(st[0]), p(st[1]), stream()), "ss_rowstat_finalize")
+    return st[0], st[1]
 
 
 def quantize_rows_fp8(x, ln=None):

@@ -546,6 +546,39 @@ def test_img_block_decode_equals_token_by_token(golden, dtype, tol):
     assert ids[3] == forced[3] and len(ids[0]) == 80 and len(ids[2]) == 80
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_prefill_batch_equals_per_slot_prefill(golden, dtype, tol):
+    """``ss_llama_prefill_batch`` (the slots' rows stacked, every projection once: weights streamed once per call) == one
+    ``ss_llama_prefill`` per slot: prompt prefill with ragged lengths, then a stacked continuation against the caches (one
+    slot sitting out), hidden rows / last-row logits / KV / lengths per slot."""
+    g, meta = golden
+    e4, wd = _engine(meta, dtype, n_seq=4)
+    e1s = [_engine(meta, dtype)[0] for _ in range(4)]
+    emb = wd["model.embed_tokens.weight"]
+    lens = [37, 21, 30, 9]
+    prompts = [synth.randint(900 + b, (lens[b],), 3, 250) for b in range(4)]
+    for b in range(4):
+        e4.select(b).reset()
+    hb = e4.prefill_batch([emb[p] for p in prompts], want_hidden=True)
+    conts = [synth.randint(910 + b, (n,), 3, 250) if n else None for b, n in enumerate([12, 0, 66, 5])]
+    hc = e4.prefill_batch([None if c is None else emb[c] for c in conts], want_hidden=True)
+    for b in range(4):
+        ref = e1s[b]
+        h1 = ref.prefill(emb[prompts[b]], want_hidden=True)
+        assert rel(hb[b], h1) < tol
+        n = lens[b]
+        if conts[b] is not None:
+            h2 = ref.prefill(emb[conts[b]], want_hidden=True)
+            assert rel(hc[b], h2) < tol
+            n += len(conts[b])
+        else:
+            assert hc[b] is None
+        e4.select(b)
+        assert e4.lengths() == ref.lengths() == (n, n)
+        assert rel(e4.logits, ref.logits) < tol
+        assert rel(e4.k_cache[:, :, :n], ref.k_cache[:, :, :n]) < tol and rel(e4.v_cache[:, :, :n], ref.v_cache[:, :, :n]) < tol
+
+
 class _ProcStub:
     """Carries the 66 image-token ids the way AutoImageTokenGenerationProcessor does (generation.py:17)."""
 

@@ -428,7 +428,7 @@ class _FakeDecodeEngine:
         self.cur, self.stop2 = 0, -1
         self._gen = [[] for _ in range(n_seq)]
         self._hid = [torch.zeros(0, 2) for _ in range(n_seq)]
-        for name in ("_img_block", "generate_img_block", "generate_batch_img_block", "img_block_enabled"):
+        for name in ("_img_block_plan", "_img_block", "generate_img_block", "generate_batch_img_block", "img_block_enabled"):
             fn = LlamaEngine.__dict__[name]
             setattr(self, name, fn.__func__ if isinstance(fn, staticmethod) else types.MethodType(fn, self))
 
@@ -467,6 +467,14 @@ class _FakeDecodeEngine:
         rows = [self._feed(self.cur, int(v)) for v in embeds[:, 0].tolist()]
         assert len(rows) <= self.max_rows
         return torch.cat(rows)
+
+    def prefill_batch(self, embeds, want_hidden=False):
+        """Stacked continuation of several slots: per slot the same rows ``prefill`` would feed."""
+        assert sum(0 if e is None else e.shape[0] for e in embeds) <= self.max_rows * self.n_seq
+        out = []
+        for b, e in enumerate(embeds):
+            out.append(None if e is None else torch.cat([self._feed(b, int(v)) for v in e[:, 0].tolist()]))
+        return out
 
     def _loop(self, b, n_steps, last, forced):
         gen, hid = [], []

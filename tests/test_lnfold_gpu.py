@@ -87,3 +87,75 @@ def test_transformer_block_lnfold_full_size_vs_oracle(name, ch, heads, res):
     print("transformer %s, LayerNorm folded: vs oracle-bf16 %.3e | vs oracle-fp32 %.3e (unfused: %.3e | %.3e; oracle bf16 vs fp32 %.3e)"
           % (name, e_bf, e_32, u_bf, u_32, theirs))
     assert e_bf < 1e-2 and e_32 <= 1.5 * theirs + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,res,bias", [(8192, 1280, 1280, True, True), (8192, 1280, 5120, True, True), (8192, 1280, 1280, False, True),
+                                             (32768, 640, 640, True, True), (32768, 640, 2560, True, True),
+                                             (2048 + 77, 1280, 1280, True, False), (1000, 640, 640, True, True),
+                                             (4096, 320, 320, False, True), (2048, 1024, 1024, True, True)])
+def test_gemm_rowstat_producer_statistics(M, N, K, res, bias):
+    """ss_gemm_rowstat + ss_rowstat_finalize: the statistics the producer's epilogue accumulates (fp64 atomics over the
+    column strips of a row) == the statistics pass over the stored output (ss_rowstats, two-pass fp32) — rstd and
+    -mean * rstd of every row, ragged M included; the output itself equals plain ss_gemm; the accumulator comes back
+    zeroed.  Rows carry a large common offset (|mean| >> std): the fp64 E[x^2] - mean^2 form must not cancel."""
+    from seedstory import ops
+    a = synth.normal_like(M + K, (M, K), 1.0).to(BF).to(DEV)
+    w = synth.normal_like(N + K + 1, (N, K), 1.0 / math.sqrt(K)).to(BF).to(DEV)
+    b = (synth.normal_like(7, (N,), 0.3) + 9.0).to(BF).to(DEV) if bias else None          # +9: |row mean| ~ 9 x std
+    r = synth.normal_like(8, (M, N), 1.0).to(BF).to(DEV) if res else None
+    acc = torch.zeros(M, 2, dtype=torch.float64, device=DEV)
+    y = ops.gemm(a, w, bias=b, residual=r, rowstat=acc)
+    y0 = ops.gemm(a, w, bias=b, residual=r)
+    assert rel(y, y0) < 2e-3                       # same arithmetic, possibly another tile (summation order)
+    yd = y.double()
+    assert rel(acc[:, 0], yd.sum(1)) < 1e-6 and rel(acc[:, 1], (yd * yd).sum(1)) < 1e-6
+    rstd, shift = ops.rowstat_finalize(acc, N, 1e-5)
+    assert float(acc.abs().max()) == 0.0           # re-zeroed for the next producer
+    r0, s0 = ops.rowstats(y, 1e-5)
+    var = yd.var(1, unbiased=False)
+    t_rstd, t_shift = 1.0 / torch.sqrt(var + 1e-5), -yd.mean(1) / torch.sqrt(var + 1e-5)
+    e = (rel(rstd, t_rstd), rel(shift, t_shift), rel(r0, t_rstd), rel(s0, t_shift))
+    print("rowstat [%d,%d,%d]: producer rstd %.2e shift %.2e | statistics pass rstd %.2e shift %.2e (vs fp64)" % ((M, N, K) + e))
+    assert e[0] < 1e-5 and e[1] < 1e-5
+    # second use of the same accumulator (finalize left it zeroed)
+    y2 = ops.gemm(a, w, bias=b, residual=r, rowstat=acc)
+    assert torch.equal(y2, y) and rel(acc[:, 0], yd.sum(1)) < 1e-6
+
+
+def test_unet_rowstat_forward_equals_statistics_pass():
+    """Tiny-but-eligible UNet (M > 128 rows per transformer): the forward with producer-carried statistics == the forward
+    whose folded norms run a statistics pass (same folded GEMMs, statistics from two different sources)."""
+    import sdxl_oracle as S
+    from seedstory import ops
+    from seedstory.diffusion import UNet2DConditionModel
+    c = S.TINY_UNET
+    m = UNet2DConditionModel(c)
+    m.load_state_dict(S.synth_weights(S.unet_shapes(c), 1), strict=False)
+    m = m.to(DEV, BF)
+    m.enable_lnfold(True)
+    x = synth.normal_like(5, (2, 4, 32, 32), 1.0).to(DEV, BF)          # 16^2 = 256 tokens x 2 at the first attention level
+    ctx = synth.normal_like(6, (2, 8, 128), 1.0).to(DEV, BF)
+    cond = {"text_embeds": synth.normal_like(7, (2, 80), 1.0).to(DEV, BF),
+            "time_ids": torch.tensor([[256, 256, 0, 0, 256, 256]] * 2, dtype=torch.float32)}
+    y1 = m(x, 801.0, ctx, added_cond_kwargs=cond).sample
+    assert any(k[0] > 128 for k in m._rs_bufs)                          # the producer path really ran
+    real = ops.rowstat_finalize
+    try:
+        # statistics pass instead: finalize still clears the accumulator, the vectors come from ss_rowstats
+        m._lin_ln_orig = m._lin_ln
+
+        def lin_ln(P, name, xx, ln, bias=None, geglu=False, rowstat=None):
+            if rowstat is not None:
+                real(rowstat, xx.shape[1], ln[2])
+            return m._lin_ln_orig(P, name, xx, ln, bias=bias, geglu=geglu, rowstat=None)
+        m._lin_ln = lin_ln
+        y2 = m(x, 801.0, ctx, added_cond_kwargs=cond).sample
+    finally:
+        del m._lin_ln
+    e = rel(y1, y2)
+    print("tiny UNet, producer statistics vs statistics pass: rel %.3e" % e)
+    assert e < 2e-2
+    m.enable_lnfold(False)
+    y3 = m(x, 801.0, ctx, added_cond_kwargs=cond).sample
+    print("tiny UNet, folded vs plain LayerNorm: rel %.3e" % rel(y1, y3))
+    assert rel(y1, y3) < 3e-2

@@ -127,12 +127,31 @@ def cmd_attn():
     json.dump(res, open(os.path.join(OUT, "attn_ab.json"), "w"), indent=0)
 
 
+def cmd_cross(UB=8):
+    """cross-attention (64 context tokens) and self-attention launches of the UNet as the forward issues them."""
+    import math
+    dt = torch.bfloat16
+    res = []
+    for (heads, L) in ((20, 1024), (10, 4096)):
+        E = heads * 64
+        q = torch.randn(UB * L, E, device=DEV, dtype=dt)
+        kv = torch.randn(UB * 64, 2 * E, device=DEV, dtype=dt)
+        qkv = torch.randn(UB * L, 3 * E, device=DEV, dtype=dt)
+        us_c = min(timed(lambda: ops.attention_q_kvpacked(q, kv, UB, L, 64, heads), n=20) for _ in range(3))
+        us_s = min(timed(lambda: ops.attention_qkv_packed(qkv, UB, L, heads), n=10) for _ in range(3))
+        row = {"B": UB, "heads": heads, "L": L, "cross_us": round(us_c, 1), "cross_GBps": round(2 * q.numel() * 2 / us_c / 1e3, 1),
+               "self_us": round(us_s, 1), "self_tflops": round(4.0 * UB * heads * L * L * 64 / us_s / 1e6, 1)}
+        print(row)
+        res.append(row)
+    json.dump(res, open(os.path.join(OUT, "cross_attn.json"), "w"), indent=0)
+
+
 def cmd_unet(UB):
     from seedstory.diffusion import UNet2DConditionModel
     dt = torch.bfloat16
     unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
-    if os.environ.get("KB_LNFOLD"):
-        unet.enable_lnfold(True)
+    if os.environ.get("KB_LNFOLD") is not None:
+        unet.enable_lnfold(os.environ["KB_LNFOLD"] != "0")
     x = torch.randn(UB, 4, 128, 128, device=DEV, dtype=dt)
     ctx = torch.randn(UB, 64, 2048, device=DEV, dtype=dt)
     cond = {"text_embeds": torch.randn(UB, 1280, device=DEV, dtype=dt),
@@ -141,9 +160,9 @@ def cmd_unet(UB):
     torch.cuda.synchronize()
     ops.softmax_rows_(torch.zeros(1, 8, device=DEV, dtype=dt), 1.0)   # marker kernel for tools/trace_summary.py
     us = min(timed(lambda: unet(x, 500.0, ctx, added_cond_kwargs=cond), n=3, warm=0) for _ in range(2))
-    out = {"lnfold": bool(os.environ.get("KB_LNFOLD")), "unet_batch": UB, "forward_ms_eager": round(us / 1e3, 2), "tflops": round(UB * 6.747e12 / (us * 1e-6) / 1e12, 1)}
+    out = {"lnfold": unet._lnfold_on(), "unet_batch": UB, "forward_ms_eager": round(us / 1e3, 2), "tflops": round(UB * 6.747e12 / (us * 1e-6) / 1e12, 1)}
     print(out)
-    json.dump(out, open(os.path.join(OUT, "unet_time_b%d.json" % UB), "w"))
+    json.dump(out, open(os.path.join(OUT, "unet_time_b%d%s.json" % (UB, "" if unet._lnfold_on() else "_nolnfold")), "w"))
 
 
 def cmd_fp8(UB):
@@ -214,6 +233,8 @@ if __name__ == "__main__":
         cmd_attn()
     elif cmd == "unet":
         cmd_unet(batch)
+    elif cmd == "cross":
+        cmd_cross(batch)
     elif cmd == "vae":
         cmd_vae()
     elif cmd == "fp8":

@@ -9,6 +9,8 @@ DEV = "cuda:0"
 dt = torch.bfloat16
 unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
 B = int(os.environ.get("SS_UNET_BATCH", "8"))
+if os.environ.get("KB_LNFOLD") is not None:
+    unet.enable_lnfold(os.environ["KB_LNFOLD"] != "0")
 x = torch.randn(B, 4, 128, 128, device=DEV, dtype=dt)
 ctx = torch.randn(B, 64, 2048, device=DEV, dtype=dt)
 cond = {"text_embeds": torch.randn(B, 1280, device=DEV, dtype=dt), "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B, dtype=torch.float32)}
