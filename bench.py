@@ -125,8 +125,17 @@ def advance_context(st, forced_ids, new_feat):
 def mllm_part(sts, eng, rin, rout, vit, kv_reuse):
     """The MLLM half of one multimodal step of every resident story (slot b of the engine = story sts[b]; all
     stories of a round are at the same step index): ``agent.generate`` of gen_george.py:189/257.  Advances the
-    stories' context (ids, image features) and returns img_gen_feat [S,256,4096]."""
+    stories' context (ids, image features) and returns img_gen_feat [S,256,4096].
+    ``eng`` may be a list of engines (groups of <= 4 lock-step slots over the SAME weight tensors — the decode GEMV
+    sweeps the weights once per group of up to 4 stories): the groups run one after the other."""
     from seedstory import ops
+    if isinstance(eng, (list, tuple)):
+        feats, i = [], 0
+        for e in eng:
+            feats.append(mllm_part(sts[i:i + e.n_seq], e, rin, rout, vit, kv_reuse))
+            i += e.n_seq
+        assert i == len(sts)
+        return feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)
     dev = sts[0].device
     embs = [None] * eng.n_seq
     for b, st in enumerate(sts):
@@ -312,6 +321,21 @@ def cpu_baseline(with_sdxl=True, diffusion_steps=30, budget_s=240.0):
                       " (resamplers excluded, < 0.1 %% of the step; wall time of this sample %.0fs)" % (time.perf_counter() - t_start)}
 
 
+def slot_groups(spg):
+    """Stories per GPU -> sizes of the lock-step decode groups (an engine sweeps the weights for <= 4 slots)."""
+    n = (spg + 3) // 4
+    return [spg // n + (1 if g < spg % n else 0) for g in range(n)]
+
+
+def build_engines(device, dtype, spg):
+    """One engine per group of <= 4 story slots, all over the same synthetic weight tensors."""
+    engs, shared = [], None
+    for n in slot_groups(spg):
+        e, shared = build_engine(device, dtype, n, shared)
+        engs.append(e)
+    return engs, shared
+
+
 def build_engine(device, dtype, n_seq, shared=None):
     """LLaMA engine over synthetic weights; `shared` = another engine's weight tensors (batch-1 engine of the same model)."""
     from seedstory.llama import LlamaEngine
@@ -418,8 +442,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the MLLM half and the render of a round back to back (default: the next round's MLLM half "
                          "runs on a second HIP stream under the current round's render)")
-    ap.add_argument("--stories-per-gpu", type=int, default=4, choices=[1, 2, 3, 4],
-                    help="stories resident per GPU, advanced in lock-step (1 = the reference's batch-1 loop)")
+    ap.add_argument("--stories-per-gpu", type=int, default=4, choices=[1, 2, 3, 4, 6, 8],
+                    help="stories resident per GPU, advanced in lock-step (1 = the reference's batch-1 loop); more than 4 "
+                         "run as groups of <= 4 decode slots over shared weights and ONE render batch (UNet batch 2 x stories)")
     ap.add_argument("--partition", choices=["replicas", "slots"], default="replicas",
                     help="N > 1: 'replicas' = independent stories per rank (throughput mode, no data-path collective); "
                          "'slots' = ONE story stream per node: rank 0 runs the MLLM recurrence, image slot t is rendered "
@@ -441,8 +466,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dist = world == 1 and bool(os.environ.get("SS_BENCH_FORCE_DIST"))   # 1-GPU box: still go through RCCL (world size 1)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if os.environ.get("SS_BENCH_SINGLE_DEVICE"):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -451,39 +478,41 @@ def main():
     global STORY_LEN
     STORY_LEN = 3 if args.mllm_only else args.story_len
     SPG = args.stories_per_gpu
-    if world > 1 and args.partition == "slots":
+    if (world > 1 or force_dist) and args.partition == "slots":
         from seedstory import parallel
         return parallel.bench_slot_partition(args, rank, world, device, dtype, sys.modules[__name__])
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng, shared = build_engine(device, dtype, SPG)
+    engs, shared = build_engines(device, dtype, SPG)
+    eng = engs[0]                                   # the roofline section profiles the first decode group
+    GRP = eng.n_seq
     rin, rout, vit = build_frontend(device, dtype)
     adapter = None if args.mllm_only else build_detokenizer(device, dtype, vit)
     if adapter is not None and args.unet_fp8:
         adapter.unet.enable_fp8(True)
-    runner = Runner(eng, rin, rout, vit, adapter, SPG, device, args, rank * 100003)
+    runner = Runner(engs if len(engs) > 1 else eng, rin, rout, vit, adapter, SPG, device, args, rank * 100003)
 
     # Tile-table entries (seedstory/tune.py) must exist before the timed region whatever --warmup is: the prompt grows
     # by 114 rows per story step (prefill GEMM M buckets of 128), and one round touches every other shape (ViT,
     # resamplers, UNet, VAE).  Shapes already in the shipped table cost nothing here.
     for i in range(STORY_LEN):
         rows = 65 if (args.kv_reuse and 0 < i < WINDOW) else prompt_len(i)
-        for b in range(SPG):
+        for b in range(GRP):
             eng.select(b).reset()
-        if SPG == 1:
+        if GRP == 1:
             eng.prefill(torch.zeros(rows, H, device=device, dtype=dtype))
-        else:                                   # the stacked prefill of the lock-step stories: M = SPG x rows
-            eng.prefill_batch([torch.zeros(rows, H, device=device, dtype=dtype)] * SPG)
-    if SPG > 1:
-        for b in range(SPG):
+        else:                                   # the stacked prefill of a lock-step group: M = GRP x rows
+            eng.prefill_batch([torch.zeros(rows, H, device=device, dtype=dtype)] * GRP)
+    if GRP > 1:
+        for b in range(GRP):
             eng.select(b).reset()
-        eng.prefill_batch([torch.zeros(66, H, device=device, dtype=dtype)] * SPG)      # the image-token block (SPG x 66 rows)
-    for b in range(SPG):
+        eng.prefill_batch([torch.zeros(66, H, device=device, dtype=dtype)] * GRP)      # the image-token block (GRP x 66 rows)
+    for b in range(GRP):
         eng.select(b).reset()
     eng.select(0)
     runner.one_step()
@@ -494,7 +523,7 @@ def main():
     runner.run(args.steps)
     barrier()
     dt_s = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt_s], dtype=torch.float64, device="cpu" if os.environ.get("SS_BENCH_SINGLE_DEVICE") else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
@@ -521,18 +550,18 @@ def main():
     # ---- roofline of the dominant kernel (decode GEMV, HBM-bound), measured live with HIP events ----
     roof = None
     if rank == 0:
-        for b in range(SPG):
+        for b in range(GRP):
             eng.select(b).set_lengths(343, 343)
         prof = eng.profile_decode(8)
         # dominant kernel = the decode weight-streaming GEMV.  With <= 2 slots per sweep the K=hidden projections
         # (qkv, o, gate|up per layer + lm_head: 97 launches/token) are ss::gemv_kernel<bf16,8,2,NB> and the down
         # projection a different symbol; with 3-4 slots every projection runs ss::gemv_ldsx_kernel<bf16,2,NB>
         # (129 launches/token), so the launch average is taken over all of them.
-        if SPG <= 2:
-            kern = "gemv_kernel<bf16_t,8,2,%d>" % SPG
+        if GRP <= 2:
+            kern = "gemv_kernel<bf16_t,8,2,%d>" % GRP
             n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
         else:
-            kern = "gemv_ldsx_kernel<bf16_t,2,%d>" % SPG
+            kern = "gemv_ldsx_kernel<bf16_t,2,%d>" % GRP
             n_launch = prof["gemv_launches"] + prof["gemv_down_launches"]
             tot_bytes = prof["gemv_bytes"] + prof["gemv_down_bytes"]
             tot_ms = prof["gemv_ms"] + prof["gemv_down_ms"]
@@ -544,7 +573,7 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py -> profiles/round2_pmc_summary.json)
         traffic, under_render_us = None, None
         pmcj = {}
-        for name in ("round2_pmc_summary.json", "round1_pmc_summary.json"):
+        for name in ("round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -552,12 +581,12 @@ def main():
                     break
                 except Exception:
                     pmcj = {}
-        if pmcj.get("stories_per_gpu") == SPG:      # counters were collected at this many slots per sweep
+        if pmcj.get("stories_per_gpu") == GRP:      # counters were collected at this many slots per sweep
             traffic = pmcj.get("gemv_hbm_traffic", {}).get(kern, {}).get("hbm_bytes_per_launch")
             under_render_us = pmcj.get("gemv_avg_us_under_render", {}).get(kern)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "ss::" + kern, "slots_per_sweep": SPG,
+                "kernel": "ss::" + kern, "slots_per_sweep": GRP,
                 "launches_per_token": n_launch, "bytes_per_launch": round(per_launch_bytes),
                 "avg_launch_us": round(per_launch_ms * 1e3, 3),
                 "avg_launch_us_note": "HIP events around every launch of un-captured decode tokens with nothing else on the "
@@ -569,7 +598,52 @@ def main():
                                                           ((prof["gemv_ms"] + prof["gemv_down_ms"]) * 1e-3) / 1e9, 1),
                          "token_ms_eager": round(prof["token_ms"], 4), "attn_ms": round(prof["attn_ms"], 4),
                          "misc_ms": round(prof["misc_ms"], 4),
-                         "weight_bytes_per_generated_token_per_story": round(13.215e9 / SPG)}}
+                         "weight_bytes_per_generated_token_per_story": round(13.215e9 / GRP)}}
+    if rank == 0 and roof is not None:
+        # the two BATCHED parts of the MLLM half (seedstory/llama.py::prefill_batch), HIP events on the stream:
+        #  * image-token block continuation: after <img> the logits processor forces 65 tokens (generation.py:19-31); the
+        #    66 rows [<img> .. </img>] of every slot of the group run as ONE stacked forward of GRP x 66 rows — HBM-bound,
+        #    the 13.2 GB of layer weights are streamed once (per group, per story step) instead of 66 x GRP times;
+        #  * prompt prefill: the group's prompts (S = 115 .. 913 each) as one stacked forward — MFMA-bound.
+        def timed_prefill(rows_per_slot, kv0, reps=3):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            z = [torch.zeros(rows_per_slot, H, device=device, dtype=dtype)] * GRP
+            tot = 0.0
+            for i in range(reps + 1):
+                for b in range(GRP):
+                    eng.select(b).set_lengths(kv0, kv0)
+                ev0.record()
+                if GRP == 1:
+                    eng.select(0).prefill(z[0])
+                else:
+                    eng.prefill_batch(z)
+                ev1.record()
+                torch.cuda.synchronize()
+                if i:
+                    tot += ev0.elapsed_time(ev1)
+            return tot / reps
+        layer_w_bytes = NL * (3 * H * H + H * H + 2 * INTER * H + H * INTER) * 2
+        blk_ms = timed_prefill(66, 343 + CAPTION)
+        roof["block_continuation"] = {
+            "what": "the 65 processor-forced image tokens of a story step: %d slots x 66 rows as one stacked forward" % GRP,
+            "bound": "hbm", "rows": GRP * 66, "ms": round(blk_ms, 3), "weight_bytes": layer_w_bytes,
+            "achieved": round(layer_w_bytes / (blk_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(layer_w_bytes / (blk_ms * 1e-3) / 8e12, 4),
+            "note": "algorithmic bytes = the 32 layers' weights once (lm_head on the last rows excluded); per story step "
+                    "this replaces 65 of the 115 decode iterations"}
+        S_big = prompt_len(STORY_LEN - 1)
+        pf_ms = timed_prefill(S_big, 0, reps=2)
+        pf_flops = GRP * S_big * (2.0 * layer_w_bytes / 2 + 4.0 * NL * H * (S_big + 1) / 2)   # projections + causal attention
+        roof["prompt_prefill"] = {
+            "what": "stacked prompt prefill of the %d lock-step stories, S = %d each (the window after step %d)" % (GRP, S_big, WINDOW - 1),
+            "bound": "mfma", "rows": GRP * S_big, "ms": round(pf_ms, 3), "flops": pf_flops,
+            "achieved": round(pf_flops / (pf_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(pf_flops / (pf_ms * 1e-3) / 2.5e15, 4)}
+        roof["tokens_per_story_step"] = {"generated": T_GEN, "iterated_in_the_device_loop": T_GEN - 65 if eng.img_block_enabled() else T_GEN,
+                                         "fed_as_one_stacked_block": 65 if eng.img_block_enabled() else 0}
+        for b in range(GRP):
+            eng.select(b).reset()
+        eng.select(0)
     if rank == 0 and adapter is not None:
         # MFMA-bound half: one SDXL-base UNet forward (batch 2S = CFG pairs of the S resident stories, 128x128
         # latents), HIP events on the stream
@@ -657,7 +731,10 @@ def main():
                                     "shape_MNK": [Mg, Ng, Kg], "avg_launch_us": round(gemm_us, 1),
                                     "achieved": round(gemm_tf, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / 2500.0, 4),
                                     "algorithmic_bytes": 2 * (Mg * Kg + Ng * Kg + Mg * Ng // 2), "traffic": ff1_traffic},
-                "note": "a round is 30 UNet forwards of batch %d (MFMA-bound) + 115 decode tokens for %d slots (HBM-bound): see mllm_decode_gemv" % (UB, SPG),
+                "note": "a round is %d UNet forwards of batch %d (MFMA-bound) + per story %d generated tokens = %d iterated decode "
+                        "tokens (weight-streaming GEMV, HBM-bound, %d slots per sweep: mllm_decode_gemv) + 65 processor-forced "
+                        "image tokens fed as one stacked block (mllm_decode_gemv.block_continuation)"
+                        % (args.diffusion_steps, UB, T_GEN, T_GEN - 65 if eng.img_block_enabled() else T_GEN, GRP),
                 "unet_fp8": fp8_leg,
                 "mllm_decode_gemv": roof_mllm}
     cpu = None
@@ -667,12 +744,14 @@ def main():
         from seedstory import tune as _tt
         total_steps = args.steps * world * SPG
         if args.mllm_only:
-            workload = ("BASELINE configs[1]: LLaMA-7B MLLM (prefill S=115/229/343 + 115 greedy decode iterations) + Qwen "
+            workload = ("BASELINE configs[1]: LLaMA-7B MLLM (prefill S=115/229/343 + 115 generated tokens per step: 50 iterated "
+                        "in the device loop + 65 processor-forced image tokens as one stacked block) + Qwen "
                         "ViT-G encode per story + input/output Resampler regression, bf16, 3 image-text pairs, no SDXL")
             metric = "story-steps/sec (text + image-feature regression, MLLM half only)"
         else:
-            workload = ("%s: full pipeline on 1 GPU per replica — LLaMA-7B MLLM (prefill S=%d..%d + 115 greedy decode "
-                        "iterations) + Qwen ViT-G encode + Resampler regression + SDXL de-tokenizer (ResamplerXLV2, %d "
+            workload = ("%s: full pipeline on 1 GPU per replica — LLaMA-7B MLLM (prefill S=%d..%d + 115 generated tokens per "
+                        "step: 50 iterated in the device loop + 65 processor-forced image tokens as one stacked block) + Qwen "
+                        "ViT-G encode + Resampler regression + SDXL de-tokenizer (ResamplerXLV2, %d "
                         "Euler steps x CFG batch 2 UNet, VAE decode) -> 1024x1024 uint8 image, bf16, story length %d, "
                         "%d-image context window (oldest pair evicted and the window re-prefilled from step %d on)"
                         % ("the metric's 10-seq StoryStream chunk (BASELINE configs[3] workload per story)" if STORY_LEN == 10
@@ -687,13 +766,16 @@ def main():
                "config": {"workload": workload, "unet_linear_dtype": "fp8_e4m3" if args.unet_fp8 else "bf16", "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
                           "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
                           "img_block_decode": bool(eng.img_block_enabled()),
-                          "img_block_decode_note": "the 65 tokens the logits processor forces behind <img> are fed as ONE batched "
-                                                   "continuation per story (same layers / attention / hidden rows / KV entries / "
-                                                   "per-position lm_head as the token-by-token loop, weights streamed once); "
-                                                   "SEEDSTORY_IMG_BLOCK=0 restores the token-by-token loop",
+                          "img_block_decode_note": "the 65 tokens the logits processor forces behind <img> are fed as ONE stacked "
+                                                   "continuation for all lock-step slots of a decode group (same layers / attention "
+                                                   "/ hidden rows / KV entries / per-position lm_head as the token-by-token loop, "
+                                                   "weights streamed once per group); the prompts are prefilled as one stacked "
+                                                   "forward too; SEEDSTORY_IMG_BLOCK=0 restores the token-by-token loop",
                           "stories_per_gpu": SPG,
                           "step_definition": "one lock-step round of the %d resident stories = %d story-steps" % (SPG, SPG),
-                          "parallelism": "story replicas x%d, %d lock-step story slots per GPU" % (world, SPG)},
+                          "decode_groups": slot_groups(SPG),
+                          "parallelism": "story replicas x%d, %d lock-step story slots per GPU (decode groups of %s over shared "
+                                         "weights, one render batch of %d)" % (world, SPG, slot_groups(SPG), 2 * SPG)},
                "batch1": batch1,
                "tile_table": {"entries": len(_tt.export_table()), "tuned_in_this_process": len(_tt.tuned_log()),
                               "note": "GEMM/conv tile choices come from seedstory/tune_gfx950.json; shapes missing from it are "
@@ -702,7 +784,7 @@ def main():
         if args.save_tune_table:
             _tt.save_table(args.save_tune_table, note="written by bench.py")
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -12,10 +12,12 @@ RCCL (backend "nccl" on ROCm; "gloo" in the CPU tests).  No all-reduce anywhere 
 
     1. runs the MLLM half of the round on its mirror of the context (KV-cached continuation: 65 new rows + 115
        decode tokens per story),
-    2. **broadcasts what the mirrors need to own a later round**: the generated token ids, the new image
-       feature(s) [S, 256, 4096] and the KV-cache rows it appended (L x 2 x [heads, rows, hd], 0.5 MiB per row:
-       ~57 MiB per story and round) — the RCCL broadcast of the MLLM KV cache over xGMI that north_star names;
-       xGMI is point-to-point, so this is N-1 link-bound copies of a few ms, issued once per round,
+    2. **broadcasts what the mirrors need to own a later round**, packed into ONE flat buffer (one collective per
+       round): the generated token ids, the new image feature(s) [S, 256, 4096] and the KV-cache rows it appended
+       (L x 2 x [heads, rows, hd], 0.5 MiB per row: ~57 MiB per story and round) — the RCCL broadcast of the MLLM KV
+       cache over xGMI that north_star names; xGMI is point-to-point, so this is N-1 link-bound copies of a few ms.
+       When the round's context update evicts an image (every round once the 8-image window is full), the next owner
+       re-prefills the window from ids + features anyway, so NO KV rows are shipped for that round,
     3. renders its S images (30 UNet steps + VAE, ~2 s) on a second stream / host thread while the next owner is
        already computing round r+1.
 
@@ -126,14 +128,49 @@ def _bcast(t, src, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+def _flat_layout(tensors):
+    """Byte offsets of the tensors inside ONE flat payload buffer (16-byte aligned pieces)."""
+    offs, off = [], 0
+    for t in tensors:
+        offs.append(off)
+        off += (t.numel() * t.element_size() + 15) // 16 * 16
+    return offs, off
+
+
+def pack_payload(tensors, device):
+    """All payload tensors of a round in ONE contiguous byte buffer: one collective per round instead of one per
+    tensor (2 + 2 S of them), and xGMI sees a single large message."""
+    offs, total = _flat_layout(tensors)
+    flat = torch.empty(max(total, 16), dtype=torch.uint8, device=device)
+    for t, o in zip(tensors, offs):
+        n = t.numel() * t.element_size()
+        if n:
+            flat[o:o + n].copy_(t.contiguous().view(-1).view(torch.uint8))
+    return flat
+
+
+def unpack_payload(flat, like):
+    """Views into ``flat`` with the shapes / dtypes of ``like`` (the mirrors' ``alloc`` result)."""
+    offs, total = _flat_layout(like)
+    assert flat.numel() >= total
+    out = []
+    for t, o in zip(like, offs):
+        n = t.numel() * t.element_size()
+        out.append(flat[o:o + n].view(t.dtype).view(t.shape) if n else t)
+    return out
+
+
 def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu", first_round=0):
     """Advance the stream by ``n_rounds`` rounds (round r is owned by rank (first_round + r) mod world).  Returns
-    the list of rounds this rank rendered.  Collective order is identical on every rank: per round one header
-    broadcast followed by one broadcast per payload tensor, all from the round's owner."""
+    the list of rounds this rank rendered.  Collective order is identical on every rank: per round ONE header
+    broadcast followed by ONE payload broadcast (all tensors packed into a flat byte buffer), both from the round's
+    owner.  The collectives are issued whenever a process group exists — also at world size 1, so that a single-GPU
+    run exercises the RCCL initialisation and broadcast path."""
     rendered = []
     pool = ThreadPoolExecutor(max_workers=1)
     pending = []
     err = []
+    comm = world > 1 or (dist.is_available() and dist.is_initialized())
 
     def render_job(r, meta, tensors):
         try:
@@ -150,14 +187,21 @@ def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu",
             assert len(meta) < META_LEN
             header[0] = len(meta)
             header[1:1 + len(meta)] = torch.tensor(list(meta), dtype=torch.int64)
-        if world > 1:
+        if comm:
             _bcast(header, owner, group)
         if rank != owner:
             meta = header[1:1 + int(header[0])].tolist()
             tensors = backend.alloc(meta)
-        if world > 1:
-            for t in tensors:
-                _bcast(t, owner, group)
+        if comm and tensors:
+            if rank == owner:
+                flat = pack_payload(tensors, tensors[0].device)
+                if flat.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+            else:
+                flat = torch.empty(max(_flat_layout(tensors)[1], 16), dtype=torch.uint8, device=tensors[0].device)
+            _bcast(flat, owner, group)
+            if rank != owner:
+                tensors = unpack_payload(flat, tensors)
         if rank == owner:
             rendered.append(r)
             pending.append(pool.submit(render_job, r, meta, tensors))
@@ -219,9 +263,14 @@ class StoryRingBackend(SlotRingBackend):
         new_embeds = torch.stack([st.image_embeds[-n_new:] for st in sts]).contiguous()        # eviction drops from the FRONT
         tensors = [ids, new_embeds]
         meta = [self.spg, ids.shape[1], n_new, int(first)]
-        for b in range(len(sts)):
+        for b, st in enumerate(sts):
             lo = 0 if full[b] else S[b] - 65
             hi = S[b] + 49                                       # rows the next continuation keeps (S_next - 65)
+            if st.evicted_last:
+                # this round's context update evicted an image: whoever owns the NEXT round re-prefills the whole window
+                # from ids + features (positions shift), so no cached row of this round is ever read again — ship none
+                # (from story step WINDOW on this is every round: 0 bytes of KV instead of 913 rows x 0.5 MiB per story)
+                lo = hi = 0
             self.eng.select(b)
             tensors += [self.eng.k_cache[:, :, lo:hi].contiguous(), self.eng.v_cache[:, :, lo:hi].contiguous()]
             meta += [lo, hi]
@@ -248,8 +297,9 @@ class StoryRingBackend(SlotRingBackend):
         for b, st in enumerate(sts):
             lo, hi = meta[4 + 2 * b], meta[5 + 2 * b]
             self.eng.select(b)
-            self.eng.k_cache[:, :, lo:hi].copy_(tensors[2 + 2 * b])
-            self.eng.v_cache[:, :, lo:hi].copy_(tensors[3 + 2 * b])
+            if hi > lo:
+                self.eng.k_cache[:, :, lo:hi].copy_(tensors[2 + 2 * b])
+                self.eng.v_cache[:, :, lo:hi].copy_(tensors[3 + 2 * b])
             # the same context update mllm_part performed on the owner (bench.advance_context)
             st.forced()                                                       # keep the story's RNG stream in step
             add = new_embeds[b]
@@ -305,6 +355,9 @@ def bench_slot_partition(args, rank, world, device, dtype, bm):
                                       % (spg, bm.STORY_LEN, world),
                           "partition": "slots", "stories_per_gpu": spg, "diffusion_steps": args.diffusion_steps,
                           "parallelism": "slot ring x%d (rotating owner, KV-cache broadcast over xGMI)" % world},
-               "rounds_rendered_by_rank0": mine, "roofline": None, "cpu_baseline": None}
+               "rounds_rendered_by_rank0": mine, "backend": dist.get_backend(),
+               "collectives_per_round": "1 header + 1 flat payload broadcast (ids, image feature, appended KV rows; no KV rows "
+                                        "for a round whose context update evicted an image)",
+               "roofline": None, "cpu_baseline": None}
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -34,6 +34,28 @@ IMG_TOKEN = '<img_{:05d}>'
 CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "configs")
 
 
+SUBTITLE_BAR = 80          # pixel height of the caption bar under the picture
+SUBTITLE_LINE = 14         # line pitch of PIL's default bitmap font as the reference spaces it
+
+
+def add_subtitle(original_image, text):
+    """Caption bar under an image, as the reference writes its ``NN.jpg`` / ``000start_image.jpg`` files
+    (gen_george.py:114-149): an RGB canvas 80 px taller than the picture, black, picture pasted at the top; the text is
+    cut in the MIDDLE OF ITS CHARACTERS (``len(text) // 2``, not at a word boundary) into two lines drawn in white with
+    PIL's default font at x = 10, the first at ``height + (80 - 14) // 2``, the second 14 px below.  Host-side PIL work
+    (the step after the path: SURVEY section 8f row 3 keeps it on the host)."""
+    from PIL import Image, ImageDraw
+    w, h = original_image.width, original_image.height
+    canvas = Image.new("RGB", (w, h + SUBTITLE_BAR), "black")
+    canvas.paste(original_image, (0, 0))
+    pen = ImageDraw.Draw(canvas)
+    half = len(text) // 2
+    y0 = h + (SUBTITLE_BAR - SUBTITLE_LINE) // 2
+    for k, line in enumerate((text[:half], text[half:])):
+        pen.text((10, y0 + k * SUBTITLE_LINE), line, fill="white")
+    return canvas
+
+
 class SyntheticTokenizer:
     """Stand-in used with --synthetic: ids 3..vocab-67 are 'text' (one id per whitespace-separated word: ``w<id>`` maps
     to ``id``, any other word to a CRC of its bytes), the last 66 ids are ``<img>``, ``<img_00000>``.., ``</img>``."""
@@ -130,6 +152,7 @@ def build(args, device, dtype):
 def run_story(args, j, question, image, tokenizer, transform, vit, agent, adapter, device, dtype):
     save_folder = os.path.join(args.out, "val_%d" % j)
     os.makedirs(save_folder, exist_ok=True)
+    add_subtitle(image, question).save(os.path.join(save_folder, "000start_image.jpg"))     # gen_george.py:161-163
     boi = tokenizer.encode(BOI_TOKEN, add_special_tokens=False)[0]
     eoi = tokenizer.encode(EOI_TOKEN, add_special_tokens=False)[0]
     img_all = tokenizer.encode(BOI_TOKEN + ''.join(IMG_TOKEN.format(i) for i in range(64)) + EOI_TOKEN, add_special_tokens=False)
@@ -163,7 +186,8 @@ def run_story(args, j, question, image, tokenizer, transform, vit, agent, adapte
             break
         images = adapter.generate(image_embeds=out['img_gen_feat'], num_inference_steps=args.diffusion_steps,
                                   height=size, width=size, input_image_size=transform.size)
-        images[0].save(os.path.join(save_folder, 'ori_{:02d}.jpg'.format(step)))
+        images[0].save(os.path.join(save_folder, 'ori_{:02d}.jpg'.format(step)))                 # :217-218
+        add_subtitle(images[0], text).save(os.path.join(save_folder, '{:02d}.jpg'.format(step)))   # :212-222
         ctx.advance(out)                                                                    # :224, :231, :235-239
     return save_folder
 

@@ -311,6 +311,19 @@ print("ok", rank)
 '''
 
 
+def test_ring_payload_pack_unpack_roundtrip():
+    """One flat byte buffer per round (one collective instead of 2 + 2 S): mixed dtypes, empty KV pieces, odd sizes."""
+    from seedstory import parallel as P
+    ts = [torch.arange(7, dtype=torch.int32).view(1, 7), torch.randn(2, 3, 5).to(torch.bfloat16), torch.empty(2, 2, 0, 4),
+          torch.randn(2, 2, 3, 4), torch.arange(3, dtype=torch.int64)]
+    flat = P.pack_payload(ts, "cpu")
+    like = [torch.empty_like(t) for t in ts]
+    back = P.unpack_payload(flat.clone(), like)
+    assert all(torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(ts, back))
+    offs, total = P._flat_layout(ts)
+    assert all(o % 16 == 0 for o in offs) and total == flat.numel()
+
+
 def test_slot_ring_world_size_2_gloo(tmp_path):
     """The multi-GPU slot ring (north_star: image slots sharded over the GPUs, MLLM KV cache broadcast): (1) the
     scheduling code of run_slot_ring with a stub engine, (2) StoryRingBackend's payload / mirror bookkeeping (KV row
