@@ -547,13 +547,20 @@ def test_img_block_decode_equals_token_by_token(golden, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-def test_prefill_batch_equals_per_slot_prefill(golden, dtype, tol):
+@pytest.mark.parametrize("stack_rows", [256, 64])
+def test_prefill_batch_equals_per_slot_prefill(golden, dtype, tol, stack_rows):
     """``ss_llama_prefill_batch`` (the slots' rows stacked, every projection once: weights streamed once per call) == one
     ``ss_llama_prefill`` per slot: prompt prefill with ragged lengths, then a stacked continuation against the caches (one
-    slot sitting out), hidden rows / last-row logits / KV / lengths per slot."""
+    slot sitting out), hidden rows / last-row logits / KV / lengths per slot.  ``stack_rows`` = the engine's
+    max_prefill_rows: 256 takes the native stacked path (97 and 83 rows), 64 the slot-by-slot fallback of the wrapper."""
+    from seedstory.llama import LlamaEngine
     g, meta = golden
-    e4, wd = _engine(meta, dtype, n_seq=4)
-    e1s = [_engine(meta, dtype)[0] for _ in range(4)]
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
+    kw = dict(hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"], dtype=dtype,
+              device=DEV, cache_cap=256, max_new=128, img_ids=_img_ids(meta))
+    e4 = LlamaEngine(wd, max_prefill_rows=stack_rows, n_seq=4, **kw)
+    e1s = [LlamaEngine(wd, max_prefill_rows=128, **kw) for _ in range(4)]
     emb = wd["model.embed_tokens.weight"]
     lens = [37, 21, 30, 9]
     prompts = [synth.randint(900 + b, (lens[b],), 3, 250) for b in range(4)]
