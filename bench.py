@@ -452,6 +452,9 @@ def main():
     ap.add_argument("--unet-fp8", action="store_true",
                     help="BASELINE configs[4]: run the UNet's transformer-block linear layers through the fp8 (OCP e4m3) "
                          "MFMA GEMM (row-wise dynamic activation scales); the headline number is the bf16 default")
+    ap.add_argument("--no-splitk", action="store_true",
+                    help="A/B: run the 128 < M <= 512 LLaMA projections (stacked image-token block, first prompts) through the "
+                         "regular GEMM tiles instead of the split-K weight-streaming path")
     ap.add_argument("--save-tune-table", default=None, help="write the GEMM tile table of this run to this JSON path")
     args = ap.parse_args()
 
@@ -475,6 +478,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = torch.bfloat16
+    if args.no_splitk:
+        from seedstory import _lib as _l
+        _l.set_tuning("gemm_splitk", 0)
     global STORY_LEN
     STORY_LEN = 3 if args.mllm_only else args.story_len
     SPG = args.stories_per_gpu

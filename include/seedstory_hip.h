@@ -79,6 +79,14 @@ int ss_get_tuning(const char* key, int dflt);
  *                        producer.  One accumulator per row count serves a whole forward: producer, finalize and
  *                        consumer follow each other on the stream. */
 int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream);
+/* Small-M weight-streaming GEMM (128 < M <= 512 rows against a LLaMA projection: the stacked image-token block of the
+ * lock-step stories, 4 x 66 rows, and their first prompts): C = A W^T (+bias)(+residual), A [M, K], W [N, K], C [M, N]
+ * contiguous.  K is split over grid.y so that every CU holds two workgroups with short K loops; fp32 partial sums go to
+ * the caller's workspace (ss_gemm_splitk_workspace_bytes; 0 = shape not eligible) and a reduce pass applies the epilogue
+ * in ss_gemm's order.  Falls back to ss_gemm when the shape is not eligible or the workspace is missing / too small. */
+size_t ss_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ss_gemm_splitk(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, const void* bias, const void* residual,
+                   void* workspace, size_t workspace_bytes, int dtype, void* stream);
 int ss_gemm_rowstat(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                     int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, double* rowstat_accum,
                     int dtype, void* stream);

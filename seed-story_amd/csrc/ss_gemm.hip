@@ -734,6 +734,101 @@ int rowstats_launch(const void* x, int64_t ld, int64_t M, int64_t K, float eps, 
     }
 }
 
+// ---- small-M weight-streaming GEMM: split-K over the pipelined tiles --------------------------------------------------
+// 128 < M <= 512 against a LLaMA projection (N x K = 4096..22016 x 4096..11008) is neither a GEMV nor a full GEMM: three
+// or four 128-row tiles cover M, so a [M, 4096, 11008] product is 96 workgroups walking 172 K tiles each (138 us, a third
+// of the CUs idle, latency-bound K loop).  Splitting K S ways gives every CU two workgroups with short K loops; the fp32
+// partial sums (S x M x N, a few MB) are folded by splitk_reduce_kernel, which applies the usual epilogue
+// (bias, rounding to T, residual) in the order of gemm_epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, int S, int M, int N, T* __restrict__ C,
+                                                            int64_t ldc, const T* __restrict__ bias, const T* __restrict__ res,
+                                                            int64_t ldr) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);     // N % 4 == 0: the 4 elements share a row
+    float4 a = *reinterpret_cast<const float4*>(P + idx);
+    for (int k = 1; k < S; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(P + (int64_t)k * M * N + idx);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (bias) v[r] += Tr<T>::ld(bias + n + r);
+        v[r] = Tr<T>::rnd(v[r]);
+        if (res) v[r] += Tr<T>::ld(res + (int64_t)m * ldr + n + r);
+        Tr<T>::st(C + (int64_t)m * ldc + n + r, v[r]);
+    }
+}
+
+// (tile, split count) of the split-K path for [M, N, K]; 0 splits = not eligible
+static void splitk_plan(int64_t M, int64_t N, int64_t K, int* cfg, int* S) {
+    *cfg = 0; *S = 0;
+    if (M <= 128 || M > 512 || N % 64 || K % 64 || K < 1024) return;
+    const int mt = cdiv(M, 128);
+    int c = 300, base = mt * cdiv(N, 128);
+    if (base < 256 || N % 128) { c = 301; base = mt * cdiv(N, 64); }
+    int s = cdiv(2 * 256, base);          // two workgroups per CU of the 256
+    const int kt = (int)(K / 64);
+    if (s > kt / 8) s = kt / 8;            // >= 8 K tiles per split: the pipeline needs a few tiles to fill
+    if (s > 8) s = 8;
+    if (s < 2) return;                     // enough workgroups without splitting: the regular path
+    while (s > 2 && (s - 1) * cdiv(kt, s) >= kt) --s;     // no empty last range
+    *cfg = c; *S = s;
+}
+
+size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    int cfg, S;
+    splitk_plan(M, N, K, &cfg, &S);
+    return S ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
+// C = A W^T (+bias)(+residual) through the split-K tiles when the shape is eligible and the workspace suffices, else ss_gemm
+template <typename T>
+int gemm_splitk_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, const void* bias,
+                       const void* residual, void* ws, size_t ws_bytes, hipStream_t s) {
+    int cfg = 0, S = 0;
+    if constexpr (Tr<T>::kVec == 8) {
+        if (tuning_get("gemm_splitk", 1)) splitk_plan(M, N, K, &cfg, &S);
+    }
+    {
+        const int force = tuning_get("gemm_splitk_s", 0);
+        if (S && force >= 2 && force <= 8 && (size_t)force * M * N * sizeof(float) > ws_bytes) S = 0;   // forced count needs the room
+    }
+    if (!S || !ws || ws_bytes < (size_t)S * M * N * sizeof(float))
+        return gemm_launch<T>(A, W, C, M, N, K, K, K, N, bias, residual, N, (bias ? SS_EPI_BIAS : 0) | (residual ? SS_EPI_RESIDUAL : 0), s);
+    if constexpr (Tr<T>::kVec == 8) {
+        GemmArgs g;
+        g.A = A; g.W = W; g.C = ws; g.bias = nullptr; g.residual = nullptr;
+        g.M = (int)M; g.N = (int)N; g.K = (int)K; g.lda = K; g.ldw = K; g.ldc = N; g.ldr = N; g.epi = 0;
+        g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
+        g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
+        // row-major tile ids (measured, profiles/round3_splitk_microbench.json: the XCD-grouped order that puts the 3 - 4 row
+        // tiles of a W column block on one XCD is 5 - 20 % SLOWER here — the row tiles then run back to back on few CUs
+        // while the W stream of the other column blocks waits; with row-major ids the repeats hit the Infinity Cache)
+        g.swz = tuning_get("gemm_splitk_swz", 0);
+        g.ksplit = S;
+        const int force = tuning_get("gemm_splitk_s", 0);
+        if (force >= 2 && force <= 8 && force <= (int)(K / 64) / 2) g.ksplit = S = force;
+        const int rc = gemm_sp_dispatch<T>(cfg, g, s);
+        if (rc) {
+            if (rc == 1) set_error("gemm_splitk: no kernel for cfg %d", cfg);
+            return rc == 1 ? SS_EINVAL : rc;
+        }
+        const int64_t quads = M * N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)ws, S, (int)M,
+                           (int)N, (T*)C, N, (const T*)bias, (const T*)residual, N);
+        SS_LAUNCH_CHECK("splitk_reduce");
+    }
+    return SS_OK;
+}
+
+int gemm_splitk_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, const void* bias,
+                    const void* residual, void* ws, size_t ws_bytes, int dtype, hipStream_t s) {
+    return SS_DISPATCH(dtype, gemm_splitk_launch, A, W, C, M, N, K, bias, residual, ws, ws_bytes, s);
+}
+
 int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
              int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, int dtype, hipStream_t s) {
     return SS_DISPATCH(dtype, gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epi, s);
@@ -764,6 +859,14 @@ int ss_gemm_rowstat(const void* A, const void* W, void* C, int64_t M, int64_t N,
     SS_REQUIRE(!(epilogue & SS_EPI_GEGLU_PAIR), "ss_gemm_rowstat: not defined for the GEGLU epilogue");
     return SS_DISPATCH(dtype, ss::gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue,
                        (hipStream_t)stream, rowstat_accum);
+}
+
+size_t ss_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) { return ss::gemm_splitk_workspace_bytes(M, N, K); }
+
+int ss_gemm_splitk(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, const void* bias, const void* residual,
+                   void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    SS_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "ss_gemm_splitk: bad arguments");
+    return ss::gemm_splitk_dev(A, W, C, M, N, K, bias, residual, workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }
 
 int ss_rowstat_finalize(double* rowstat, int64_t M, int64_t width, float eps, float* rstd_out, float* shift_out, void* stream) {

@@ -123,6 +123,10 @@ struct GemmArgs {
     // (rounded to T, residual included) into rowstat_out[2m], rowstat_out[2m+1] — fp64 atomics, one pair per row per
     // column strip of a wave; ss_rowstat_finalize turns them into (rstd, shift) and re-zeroes the array.
     double* rowstat_out = nullptr;
+    // split-K (kernels instantiated with SPLITK, grid.y = ksplit): workgroup (x, y) multiplies K tiles
+    // [y * ktiles_per_split, ...) and stores its raw fp32 accumulators to ((float*)C)[y][m][n] (ldc = N);
+    // splitk_reduce_kernel sums the slices and applies the epilogue
+    int ksplit = 1;
 };
 
 // Linear workgroup id -> output tile.  MI355X deals workgroups to its 8 XCDs round-robin by linear workgroup id and
@@ -317,6 +321,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// split-K partial result: the raw fp32 accumulators of this workgroup's K range -> P[split][m][n] (row stride N)
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_partial(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
+                                                      int l15, int grp, int split) {
+    float* __restrict__ P = (float*)g.C + (int64_t)split * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n0 = n_base + i * 16 + grp * 4;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m_base + j * 16 + l15;
+            if (m >= g.M) continue;
+            float* o = P + (int64_t)m * g.N + n0;
+            if (n0 + 3 < g.N) {
+                *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n0 + r < g.N) o[r] = acc[i][j][r];
+            }
+        }
     }
 }
 

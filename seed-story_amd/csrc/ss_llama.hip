@@ -27,6 +27,9 @@ int gemv_dev(const void* W, const void* x, void* y, int64_t N, int64_t K, const 
 int gemv_batched_dev(const void* W, const void* x, void* y, int64_t N, int64_t K, const void* norm_w, float eps,
                      const void* bias, const void* residual, int epi, const int32_t* done_flag, int done_stride,
                      int nb, int64_t x_ld, int64_t y_ld, int64_t res_ld, int dtype, hipStream_t s);
+size_t gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_splitk_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, const void* bias,
+                    const void* residual, void* ws, size_t ws_bytes, int dtype, hipStream_t s);
 int gemm_dev(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
              int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, int dtype, hipStream_t s);
 int rope_kv_append_dev(const void* qkv, void* q_out, void* kc, void* vc, const void* cos_t, const void* sin_t,
@@ -150,6 +153,16 @@ int rmsnorm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t co
 
 using namespace ss;
 
+struct ss_llama;
+// one projection of the prefill paths: C [M, N] = A [M, K] W^T (+ residual).  128 < M <= 512 rows (the stacked image-token
+// block, the first prompts) take the split-K weight-streaming path when the engine carved a partial-sum workspace for it.
+static int prefill_proj(void* splitk_ws, size_t splitk_bytes, const void* A, const void* W, void* C, int64_t M, int64_t N,
+                        int64_t K, const void* residual, int dt, hipStream_t s) {
+    if (splitk_ws && M > 128 && M <= 512)
+        return gemm_splitk_dev(A, W, C, M, N, K, nullptr, residual, splitk_ws, splitk_bytes, dt, s);
+    return gemm_dev(A, W, C, M, N, K, K, K, N, nullptr, residual, N, residual ? SS_EPI_RESIDUAL : SS_EPI_NONE, dt, s);
+}
+
 struct SeqGraph {
     int seq0, nb;
     hipGraph_t graph;
@@ -176,6 +189,8 @@ struct ss_llama {
     char* logits;            // [n_seq][vocab]
     char *x, *xn, *qkv, *q, *attn, *gu, *hm;  // activations ([max_rows][..]); decode uses rows 0..nb-1
     float* attn_ws;          // [n_seq] split-KV partial slabs
+    void* splitk_ws;         // fp32 partial sums of the small-M split-K projections (128 < rows <= 512)
+    size_t splitk_bytes;
     // host mirrors
     std::vector<int64_t> kv_len, pos;
     hipStream_t cap_stream;
@@ -211,6 +226,18 @@ static void carve(ss_llama* h, Carver& c) {
     h->gu = c.take(R * 2 * I * e);
     h->hm = c.take(R * I * e);
     h->attn_ws = (float*)c.take(S * ss_attn_decode_workspace_bytes(g.n_heads, h->hd));
+    // split-K partial sums: the largest need over the four projections at the largest eligible row count
+    size_t sk = 0;
+    if (g.dtype != SS_F32 && R > 128) {
+        const int64_t Mx = R < 512 ? (int64_t)R : 512;
+        const int64_t shapes[4][2] = {{3 * (int64_t)H, (int64_t)H}, {(int64_t)H, (int64_t)H}, {2 * (int64_t)I, (int64_t)H}, {(int64_t)H, (int64_t)I}};
+        for (auto& nk : shapes) {
+            const size_t b = gemm_splitk_workspace_bytes(Mx, nk[0], nk[1]);
+            if (b > sk) sk = b;
+        }
+    }
+    h->splitk_bytes = sk;
+    h->splitk_ws = sk ? c.take(sk) : nullptr;
 }
 
 static int cfg_n_seq(const ss_llama_config* cfg) { return cfg->n_seq > 0 ? cfg->n_seq : 1; }
@@ -535,20 +562,18 @@ int ss_llama_prefill(ss_llama* h, const void* embeds, int64_t M, const int32_t* 
         char* kc = kbase + (size_t)l * plane;
         char* vc = vbase + (size_t)l * plane;
         if ((rc = rmsnorm_rows(h->x, L.ln1, h->xn, M, H, g.rms_eps, dt, s))) return rc;
-        if ((rc = gemm_dev(h->xn, L.wqkv, h->qkv, M, 3 * H, H, H, H, 3 * H, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
-            return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->xn, L.wqkv, h->qkv, M, 3 * H, H, nullptr, dt, s))) return rc;
         if ((rc = ss_rope_kv_append(h->qkv, h->q, kc, vc, h->w.rope_cos, h->w.rope_sin, pos_ids, cur_pos, M, g.n_heads,
                                     hd, kv0, g.cache_cap, dt, stream)))
             return rc;
         if ((rc = ss_attention(h->q, kc, vc, h->attn, 1, g.n_heads, M, kv1, hd, 0, hd, H, 0, (int64_t)g.cache_cap * hd,
                                hd, 0, (int64_t)g.cache_cap * hd, hd, 0, hd, H, 1.0f / sqrtf((float)hd), 1, dt, stream)))
             return rc;
-        if ((rc = gemm_dev(h->attn, L.wo, h->x, M, H, H, H, H, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->attn, L.wo, h->x, M, H, H, h->x, dt, s))) return rc;
         if ((rc = rmsnorm_rows(h->x, L.ln2, h->xn, M, H, g.rms_eps, dt, s))) return rc;
-        if ((rc = gemm_dev(h->xn, L.wgu, h->gu, M, 2 * I, H, H, H, 2 * I, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
-            return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->xn, L.wgu, h->gu, M, 2 * I, H, nullptr, dt, s))) return rc;
         if ((rc = ss_silu_mul(h->gu, h->hm, M, I, dt, stream))) return rc;
-        if ((rc = gemm_dev(h->hm, L.wdown, h->x, M, H, I, I, I, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->hm, L.wdown, h->x, M, H, I, h->x, dt, s))) return rc;
     }
     // final norm (:652) for all rows, lm_head for the last row only (greedy consumes logits[:, -1])
     void* hid = hidden_out ? hidden_out : (void*)h->xn;
@@ -592,8 +617,7 @@ int ss_llama_prefill_batch(ss_llama* h, const void* embeds, const int64_t* host_
     for (int l = 0; l < g.n_layers; ++l) {
         const ss_llama_layer_weights& L = h->layers[l];
         if ((rc = rmsnorm_rows(h->x, L.ln1, h->xn, M, H, g.rms_eps, dt, s))) return rc;
-        if ((rc = gemm_dev(h->xn, L.wqkv, h->qkv, M, 3 * H, H, H, H, 3 * H, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
-            return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->xn, L.wqkv, h->qkv, M, 3 * H, H, nullptr, dt, s))) return rc;
         int64_t r0 = 0;
         for (int b = 0; b < h->n_seq; ++b) {
             const int64_t r = host_rows[b];
@@ -612,12 +636,11 @@ int ss_llama_prefill_batch(ss_llama* h, const void* embeds, const int64_t* host_
                 return rc;
             r0 += r;
         }
-        if ((rc = gemm_dev(h->attn, L.wo, h->x, M, H, H, H, H, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->attn, L.wo, h->x, M, H, H, h->x, dt, s))) return rc;
         if ((rc = rmsnorm_rows(h->x, L.ln2, h->xn, M, H, g.rms_eps, dt, s))) return rc;
-        if ((rc = gemm_dev(h->xn, L.wgu, h->gu, M, 2 * I, H, H, H, 2 * I, nullptr, nullptr, 0, SS_EPI_NONE, dt, s)))
-            return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->xn, L.wgu, h->gu, M, 2 * I, H, nullptr, dt, s))) return rc;
         if ((rc = ss_silu_mul(h->gu, h->hm, M, I, dt, stream))) return rc;
-        if ((rc = gemm_dev(h->hm, L.wdown, h->x, M, H, I, I, I, H, nullptr, h->x, H, SS_EPI_RESIDUAL, dt, s))) return rc;
+        if ((rc = prefill_proj(h->splitk_ws, h->splitk_bytes, h->hm, L.wdown, h->x, M, H, I, h->x, dt, s))) return rc;
     }
     void* hid = hidden_out ? hidden_out : (void*)h->xn;
     if ((rc = rmsnorm_rows(h->x, h->w.final_norm, hid, M, H, g.rms_eps, dt, s))) return rc;

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "ss_gemm_lnfold": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "ss_gemm_rowstat": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
     "ss_rowstat_finalize": (C.c_int, [vp, i64, i64, f32, vp, vp, vp]),
+    "ss_gemm_splitk_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
+    "ss_gemm_splitk": (C.c_int, [vp, vp, vp, i64, i64, i64, vp, vp, vp, C.c_size_t, C.c_int, vp]),
     "ss_quantize_rows_fp8": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, f32, C.c_int, vp]),
     "ss_gemm_fp8": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp]),
     "ss_create": (C.c_int, [C.c_int, C.POINTER(vp)]),

@@ -171,6 +171,18 @@ def gemm(a, w, bias=None, residual=None, gelu=False, out=None, rowstat=None):
     return out
 
 
+def gemm_splitk(a, w, bias=None, residual=None):
+    """Small-M weight-streaming GEMM (ss_gemm_splitk): a [M, K] @ w[N, K]^T for 128 < M <= 512; falls back to ss_gemm."""
+    _req(a); _req(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    nbytes = lib().ss_gemm_splitk_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=a.device)
+    check(lib().ss_gemm_splitk(p(a), p(w), p(out), M, N, K, p(bias), p(residual), p(ws), nbytes, dt(a), stream()), "ss_gemm_splitk")
+    return out
+
+
 def gemm_geglu(a, w_pairs, bias_pairs):
     """a [M, K] @ w_pairs[2D, K]^T with rows interleaved (value_i, gate_i) -> [M, D] = value * gelu(gate)."""
     _req(a); _req(w_pairs)

@@ -402,3 +402,34 @@ def test_small_elementwise(ops, dtype):
     assert torch.equal(col[:, :588].float(), ref) and float(col[:, 588:].abs().sum()) == 0
     xl = synth.normal_like(38, (2, 16, 256), 1.0, dtype=dtype)
     assert rel(ops.l2normalize_dim1(dev(xl)), torch.nn.functional.normalize(xl.float())) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("M,N,K,res,bias", [(264, 12288, 4096, False, False), (264, 4096, 4096, True, False), (264, 22016, 4096, False, False),
+                                             (264, 4096, 11008, True, True), (460, 12288, 4096, False, True), (130, 4096, 4096, True, False),
+                                             (512, 4096, 11008, True, False), (300, 1024, 2048, False, False), (66, 4096, 4096, True, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_gemm_splitk_small_m_weight_streaming(M, N, K, res, bias, dtype):
+    """ss_gemm_splitk (128 < M <= 512 against LLaMA-sized projections: K split over grid.y, fp32 partial sums, reduce pass
+    with the epilogue) vs fp32 math on the same operands; shapes outside its range and fp32 fall back to ss_gemm."""
+    from seedstory import _lib, ops
+    import math
+    a = synth.normal_like(M + 1, (M, K), 1.0, dtype=dtype).to(DEV)
+    w = synth.normal_like(N + 2, (N, K), 1.0 / math.sqrt(K), dtype=dtype).to(DEV)
+    b = synth.normal_like(3, (N,), 0.5, dtype=dtype).to(DEV) if bias else None
+    r = synth.normal_like(4, (M, N), 1.0, dtype=dtype).to(DEV) if res else None
+    y = ops.gemm_splitk(a, w, bias=b, residual=r)
+    ref = a.float() @ w.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    if r is not None:
+        ref = ref.to(dtype).float() + r.float()
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    assert rel(y, ref) < tol
+    nb = _lib.lib().ss_gemm_splitk_workspace_bytes(M, N, K)
+    assert nb % (M * N * 4) == 0                            # S slices of fp32 partial sums (0 = not eligible: plain ss_gemm)
+    if (M, N, K) in ((264, 4096, 4096), (264, 4096, 11008), (264, 12288, 4096), (512, 4096, 11008)):
+        assert nb >= 2 * M * N * 4
+    if M <= 128 or (M, N, K) == (264, 22016, 4096):
+        assert nb == 0
+    y0 = ops.gemm(a, w, bias=b, residual=r)
+    assert rel(y, y0) < tol
