@@ -767,8 +767,11 @@ static void splitk_plan(int64_t M, int64_t N, int64_t K, int* cfg, int* S) {
     *cfg = 0; *S = 0;
     if (M <= 128 || M > 512 || N % 64 || K % 64 || K < 1024) return;
     const int mt = cdiv(M, 128);
-    int c = 300, base = mt * cdiv(N, 128);
-    if (base < 256 || N % 128) { c = 301; base = mt * cdiv(N, 64); }
+    // measured (profiles/round3_splitk.txt): with >= 256 workgroups of 128x128 already ([M, 12288, 4096]: 288 - 384) splitting
+    // K gains nothing or loses (61 vs 63 us at 264 rows, 74 vs 64 at 460); it pays where the column count leaves most CUs
+    // idle (N = 4096: 96 - 128 workgroups): 128x64 tiles x 2 - 3 K ranges
+    if (mt * cdiv(N, 128) >= 256) return;
+    int c = 301, base = mt * cdiv(N, 64);
     int s = cdiv(2 * 256, base);          // two workgroups per CU of the 256
     const int kt = (int)(K / 64);
     if (s > kt / 8) s = kt / 8;            // >= 8 K tiles per split: the pipeline needs a few tiles to fill
