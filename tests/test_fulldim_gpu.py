@@ -146,6 +146,101 @@ def test_llama_full_width_prefill_continuation_decode(dtype, n_seq):
             assert ours <= 1.5 * theirs + 1e-3, (key, ours, theirs)
 
 
+def test_llama_7b_all_32_layers():
+    """The WHOLE LLaMA-2-7B configuration (4096 / 32 heads / 32 layers / 11008 / 32066: 6.74 B parameters) — the depth the
+    2-layer tests above do not cover: prefill S = 64, a 66-row image-token-block-sized continuation and 3 graph-decoded
+    tokens, fp32 (exact-fp32 MFMA mode) and bf16, against the oracle on the host.  Weights: seeded torch generator in fp32,
+    bf16 = their rounding (both sides take the SAME tensors).  bf16 over 32 layers is gated by the oracle's own
+    bf16-vs-fp32 distance."""
+    import time
+    from seedstory.llama import LlamaEngine
+    NL32 = 32
+    t0 = time.time()
+    g = torch.Generator().manual_seed(4242)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g) * 0.02
+    w32 = {"model.embed_tokens.weight": rnd(VOCAB, H), "lm_head.weight": rnd(VOCAB, H), "model.norm.weight": 1.0 + 0.1 * torch.randn(H, generator=g)}
+    for l in range(NL32):
+        p_ = "model.layers.%d." % l
+        for n, (o, i) in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)), ("self_attn.o_proj", (H, H)),
+                          ("mlp.gate_proj", (INTER, H)), ("mlp.up_proj", (INTER, H)), ("mlp.down_proj", (H, INTER))):
+            w32[p_ + n + ".weight"] = rnd(o, i)
+        w32[p_ + "input_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+        w32[p_ + "post_attention_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+    wbf = {k: v.to(torch.bfloat16) for k, v in w32.items()}
+    w32 = {k: v.float() for k, v in wbf.items()}                    # fp32 master = the bf16-representable values
+    t_w = time.time() - t0
+    dims = O.LlamaDims(H, NH, NL32, INTER, VOCAB)
+    prompt = synth.randint(741, (64,), 3, 32000)
+    cont = synth.randint(742, (66,), 3, 32000)
+    forced = synth.randint(743, (4,), 3, 32000).tolist()
+    t0 = time.time()
+    with torch.no_grad():
+        r32 = _oracle_run(w32, dims, w32["model.embed_tokens.weight"], prompt, cont, forced)
+        rbf = _oracle_run(wbf, dims, wbf["model.embed_tokens.weight"], prompt, cont, forced)
+    t_o = time.time() - t0
+    res = {}
+    for dtype, wd in ((torch.float32, w32), (torch.bfloat16, wbf)):
+        eng = LlamaEngine(wd, hidden=H, n_heads=NH, n_layers=NL32, inter=INTER, vocab=VOCAB, dtype=dtype, device=DEV,
+                          cache_cap=256, max_new=16, max_prefill_rows=128, img_ids=IMG_IDS)
+        emb = wd["model.embed_tokens.weight"]
+        hid = eng.prefill(emb[prompt], want_hidden=True)
+        lg1 = eng.logits.float().cpu().clone()
+        hid2 = eng.prefill(emb[cont], want_hidden=True)
+        lg2 = eng.logits.float().cpu().clone()
+        n = eng.generate(4, last_prompt_id=int(cont[-1]), forced=forced)
+        assert n == 4 and eng.gen_ids[:4].tolist() == forced
+        res[dtype] = {"prefill_hidden": hid.float().cpu(), "prefill_logits": lg1, "cont_hidden": hid2.float().cpu(), "cont_logits": lg2,
+                      "decode_hidden": eng.hidden_rows[:3].float().cpu(), "k31": eng.k_cache[31, :, :eng.lengths()[0]].float().cpu()}
+        del eng
+        torch.cuda.empty_cache()
+    print("LLaMA-2-7B, all 32 layers (weights %.0f s, host oracle fp32 + bf16 %.0f s):" % (t_w, t_o))
+    for key in ("prefill_hidden", "prefill_logits", "cont_hidden", "cont_logits", "decode_hidden"):
+        e32 = rel(res[torch.float32][key], r32[key])
+        ebf, e_bf32, theirs = rel(res[torch.bfloat16][key], rbf[key]), rel(res[torch.bfloat16][key], r32[key]), rel(rbf[key], r32[key])
+        print("  %-15s fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e"
+              % (key, e32, ebf, e_bf32, theirs))
+        assert e32 < 1e-4, (key, e32)
+        assert e_bf32 <= 1.5 * theirs + 2e-3, (key, e_bf32, theirs)
+        assert ebf <= 2.5 * theirs + 2e-3, (key, ebf, theirs)
+
+
+def test_vit_g_all_48_blocks():
+    """The WHOLE Qwen ViT-G (448^2, patch 14, width 1664, 48 blocks x 16 heads, MLP 8192, attn_pool to 256 x 4096: 1.9 B
+    parameters) on one image, fp32 and bf16, against the oracle on the host (4.1 TFLOP: ~10 s).  The 1-block test above is
+    pinned on the real reference class; this one covers the depth."""
+    import time
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    c = dict(width=1664, layers=48, heads=16, mlp_width=8192, patch=14, out_dim=4096, n_queries=256, image=448)
+    t0 = time.time()
+    wd = synth.vit_weights(33, c["width"], c["layers"], c["heads"], c["mlp_width"], c["patch"], c["out_dim"], c["n_queries"])
+    wbf = {k: v.to(torch.bfloat16) for k, v in wd.items()}
+    w32 = {k: v.float() for k, v in wbf.items()}
+    x = synth.normal_like(133, (1, 3, c["image"], c["image"]), 1.0).to(torch.bfloat16)
+    kw = dict(width=c["width"], layers=c["layers"], heads=c["heads"], patch=c["patch"], out_dim=c["out_dim"], n_queries=c["n_queries"])
+    with torch.no_grad():
+        r32 = O.vit_forward(w32, x.float(), **kw)
+        rbf = O.vit_forward(wbf, x, **kw)
+    t_o = time.time() - t0
+    out = {}
+    for dtype, w in ((torch.float32, w32), (torch.bfloat16, wbf)):
+        m = VisionTransformerWithAttnPool(image_size=c["image"], patch_size=c["patch"], width=c["width"], layers=c["layers"],
+                                          heads=c["heads"], mlp_ratio=4.9231, n_queries=c["n_queries"], output_dim=c["out_dim"])
+        missing, unexpected = m.load_state_dict(w, strict=False)
+        assert not missing and not unexpected
+        m = m.to(DEV, dtype)
+        out[dtype] = m(x.to(DEV, dtype)).float().cpu()
+        del m
+        torch.cuda.empty_cache()
+    e32 = rel(out[torch.float32], r32)
+    ebf, e_bf32, theirs = rel(out[torch.bfloat16], rbf), rel(out[torch.bfloat16], r32), rel(rbf, r32)
+    print("ViT-G, all 48 blocks + attn_pool (weights + host oracle %.0f s): fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, "
+          "HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e" % (t_o, e32, ebf, e_bf32, theirs))
+    assert out[torch.float32].shape == (1, 256, 4096) and e32 < 1e-4
+    assert e_bf32 <= 1.5 * theirs + 2e-3 and ebf <= 2.5 * theirs + 2e-3
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (b) ViT-G-width block
 # ---------------------------------------------------------------------------------------------------------------------
