@@ -146,6 +146,33 @@ def test_llama_full_width_prefill_continuation_decode(dtype, n_seq):
             assert ours <= 1.5 * theirs + 1e-3, (key, ours, theirs)
 
 
+_W7B = {}
+
+
+def _llama7b_weights():
+    """LLaMA-2-7B-shaped weights (6.74 B parameters): seeded torch generator, fp32 master = the bf16-representable values
+    (both sides of every comparison take THESE tensors).  Cached for the module (27 + 13.5 GB of host memory)."""
+    if not _W7B:
+        import time
+        t0 = time.time()
+        g = torch.Generator().manual_seed(4242)
+
+        def rnd(*s):
+            return torch.randn(*s, generator=g) * 0.02
+        w = {"model.embed_tokens.weight": rnd(VOCAB, H), "lm_head.weight": rnd(VOCAB, H), "model.norm.weight": 1.0 + 0.1 * torch.randn(H, generator=g)}
+        for l in range(32):
+            p_ = "model.layers.%d." % l
+            for n, (o, i) in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)), ("self_attn.o_proj", (H, H)),
+                              ("mlp.gate_proj", (INTER, H)), ("mlp.up_proj", (INTER, H)), ("mlp.down_proj", (H, INTER))):
+                w[p_ + n + ".weight"] = rnd(o, i)
+            w[p_ + "input_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+            w[p_ + "post_attention_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+        _W7B["bf"] = {k: v.to(torch.bfloat16) for k, v in w.items()}
+        _W7B["f32"] = {k: v.float() for k, v in _W7B["bf"].items()}
+        _W7B["t"] = time.time() - t0
+    return _W7B["f32"], _W7B["bf"], _W7B["t"]
+
+
 def test_llama_7b_all_32_layers():
     """The WHOLE LLaMA-2-7B configuration (4096 / 32 heads / 32 layers / 11008 / 32066: 6.74 B parameters) — the depth the
     2-layer tests above do not cover: prefill S = 64, a 66-row image-token-block-sized continuation and 3 graph-decoded
@@ -155,22 +182,7 @@ def test_llama_7b_all_32_layers():
     import time
     from seedstory.llama import LlamaEngine
     NL32 = 32
-    t0 = time.time()
-    g = torch.Generator().manual_seed(4242)
-
-    def rnd(*s):
-        return torch.randn(*s, generator=g) * 0.02
-    w32 = {"model.embed_tokens.weight": rnd(VOCAB, H), "lm_head.weight": rnd(VOCAB, H), "model.norm.weight": 1.0 + 0.1 * torch.randn(H, generator=g)}
-    for l in range(NL32):
-        p_ = "model.layers.%d." % l
-        for n, (o, i) in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)), ("self_attn.o_proj", (H, H)),
-                          ("mlp.gate_proj", (INTER, H)), ("mlp.up_proj", (INTER, H)), ("mlp.down_proj", (H, INTER))):
-            w32[p_ + n + ".weight"] = rnd(o, i)
-        w32[p_ + "input_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
-        w32[p_ + "post_attention_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
-    wbf = {k: v.to(torch.bfloat16) for k, v in w32.items()}
-    w32 = {k: v.float() for k, v in wbf.items()}                    # fp32 master = the bf16-representable values
-    t_w = time.time() - t0
+    w32, wbf, t_w = _llama7b_weights()
     dims = O.LlamaDims(H, NH, NL32, INTER, VOCAB)
     prompt = synth.randint(741, (64,), 3, 32000)
     cont = synth.randint(742, (66,), 3, 32000)
@@ -239,6 +251,109 @@ def test_vit_g_all_48_blocks():
           "HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e" % (t_o, e32, ebf, e_bf32, theirs))
     assert out[torch.float32].shape == (1, 256, 4096) and e32 < 1e-4
     assert e_bf32 <= 1.5 * theirs + 2e-3 and ebf <= 2.5 * theirs + 2e-3
+
+
+def test_story_three_steps_full_size_mllm_half():
+    """BASELINE configs[1] at REAL size, end to end through the reference API surface: whole ViT-G (48 blocks) on the start
+    image -> 3 story steps of ``ContinuousLVLM.generate`` on the whole LLaMA-2-7B (32 layers) with the full-size input /
+    output resamplers, the context growing by caption + image tokens and the regressed feature each step
+    (gen_george.py:168-243 on token ids).  Captions are teacher-forced (random weights never open an image), so the oracle
+    evaluates each step as ONE causal pass over prompt + forced tokens — the same function as the token-by-token loop.
+    Compared: ``img_gen_feat`` [1, 256, 4096] of every step, fp32 and bf16 (gated by the oracle's own bf16 distance)."""
+    import time
+    from src.models.qwen_visual import Resampler, VisionTransformerWithAttnPool
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    from src.models_clm.models import ContinuousLVLM
+    w32, wbf, _ = _llama7b_weights()
+    vc = dict(width=1664, layers=48, heads=16, mlp_width=8192, patch=14, out_dim=4096, n_queries=256)
+    vit_bf = {k: v.to(torch.bfloat16) for k, v in synth.vit_weights(33, vc["width"], vc["layers"], vc["heads"], vc["mlp_width"], vc["patch"],
+                                                                      vc["out_dim"], vc["n_queries"]).items()}
+    rin_bf = {k: v.to(torch.bfloat16) for k, v in synth.resampler_weights(21, "", 8, H).items()}
+    rout_bf = {k: v.to(torch.bfloat16) for k, v in synth.resampler_weights(22, "", 16, H).items()}
+    img = synth.normal_like(134, (1, 3, 448, 448), 1.0).to(torch.bfloat16)
+    CAP, STEPS = 8, 3
+    caps = [synth.randint(750 + i, (CAP,), 3, 32000).tolist() for i in range(STEPS + 1)]
+    boi, eoi = IMG_IDS[0], IMG_IDS[-1]
+    dims = O.LlamaDims(H, NH, 32, INTER, VOCAB)
+    vkw = dict(width=vc["width"], layers=vc["layers"], heads=vc["heads"], patch=vc["patch"], out_dim=vc["out_dim"], n_queries=vc["n_queries"])
+
+    def to(d, dtype):
+        return {k: v.to(dtype) for k, v in d.items()}
+
+    def context(ids):
+        pos = [i + 1 for i, t in enumerate(ids) if t == boi]
+        mask = torch.zeros(1, len(ids), dtype=torch.bool)
+        for p_ in pos:
+            mask[0, p_:p_ + 64] = True
+        return mask
+
+    def oracle_story(dtype):
+        wl = w32 if dtype == torch.float32 else wbf
+        wv, wi, wo = to(vit_bf, dtype), to(rin_bf, dtype), to(rout_bf, dtype)
+        feats = []
+        with torch.no_grad():
+            embeds = O.vit_forward(wv, img.to(dtype), **vkw)                                   # [1, 256, 4096]
+            ids = [1] + caps[0] + IMG_IDS
+            for st in range(STEPS):
+                forced = caps[st + 1] + IMG_IDS + [2]
+                mask = context(ids)
+                x = wl["model.embed_tokens.weight"][torch.tensor([ids + forced[:-1]])].clone()
+                lm = O.resampler_forward(wi, "", embeds, 32)
+                x[0, :len(ids)][mask[0]] = lm.reshape(-1, H)
+                S, T = len(ids), len(forced)
+                _, hid, _ = O.llama_forward(wl, dims, x, torch.arange(S + T - 1)[None], None, all_logits=False)
+                rows = hid[0, S - 1:]                      # row j = state whose input was generated id j - 1 ... (models.py:182-184)
+                e = CAP + 65                               # index of </img> in the generated ids
+                feat = O.resampler_forward(wo, "", rows[e - 64 + 1:e + 1][None], 32)   # inputs <img_00000> .. <img_00063>
+                feats.append(feat.float())
+                ids = ids + forced[:CAP] + IMG_IDS
+                embeds = torch.cat([embeds, feat], dim=0)
+        return feats
+
+    def hip_story(dtype):
+        cfg = LlamaConfig(hidden_size=H, intermediate_size=INTER, num_hidden_layers=32, num_attention_heads=NH, vocab_size=VOCAB)
+        llm = LlamaForCausalLM(cfg)
+        missing, unexpected = llm.load_state_dict(w32 if dtype == torch.float32 else wbf, strict=False)
+        assert not missing and not unexpected
+        llm.cache_cap, llm.max_new, llm.max_prefill_rows = 512, 128, 512
+        llm.use_kv_cache_head = False
+        rin = Resampler(grid_size=8, embed_dim=H, num_heads=32, kv_dim=H)
+        rin.load_state_dict(rin_bf)
+        rout = Resampler(grid_size=16, embed_dim=H, num_heads=32, kv_dim=H)
+        rout.load_state_dict(rout_bf)
+        agent = ContinuousLVLM(llm, rin, rout).eval().to(DEV, dtype)
+        vit = VisionTransformerWithAttnPool(image_size=448, patch_size=14, width=vc["width"], layers=vc["layers"], heads=vc["heads"],
+                                            mlp_ratio=4.9231, n_queries=256, output_dim=4096)
+        vit.load_state_dict(vit_bf, strict=False)
+        vit = vit.to(DEV, dtype)
+        feats = []
+        embeds = vit(img.to(DEV, dtype))
+        ids = [1] + caps[0] + IMG_IDS
+        for st in range(STEPS):
+            forced = caps[st + 1] + IMG_IDS + [2]
+            out = agent.generate(tokenizer=_Tok(IMG_IDS), input_ids=torch.tensor([ids]), image_embeds=embeds,
+                                 embeds_cmp_mask=torch.ones(embeds.shape[0], dtype=torch.bool), ids_cmp_mask=context(ids),
+                                 max_new_tokens=120, num_img_gen_tokens=64, forced_tokens=forced)
+            assert out["generate_ids"].tolist() == forced and out["has_img_output"]
+            feats.append(out["img_gen_feat"].float().cpu())
+            ids = ids + forced[:CAP] + IMG_IDS
+            embeds = torch.cat([embeds, out["img_gen_feat"]], dim=0)                           # gen_george.py:224
+        del agent, vit, llm
+        torch.cuda.empty_cache()
+        return feats
+
+    t0 = time.time()
+    o32, obf = oracle_story(torch.float32), oracle_story(torch.bfloat16)
+    t_o = time.time() - t0
+    h32, hbf = hip_story(torch.float32), hip_story(torch.bfloat16)
+    print("3-step story, MLLM half at real size (ViT-G 48 blocks, LLaMA-2-7B 32 layers, resamplers 4096 / 32 heads; host oracle %.0f s):" % t_o)
+    for st in range(STEPS):
+        e32 = rel(h32[st], o32[st])
+        ebf, e_bf32, theirs = rel(hbf[st], obf[st]), rel(hbf[st], o32[st]), rel(obf[st], o32[st])
+        print("  step %d img_gen_feat: fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e"
+              % (st + 1, e32, ebf, e_bf32, theirs))
+        assert h32[st].shape == (1, 256, H) and e32 < 1e-3            # the north-star gate, at real size, end to end
+        assert e_bf32 <= 1.5 * theirs + 2e-3 and ebf <= 2.5 * theirs + 2e-3
 
 
 # ---------------------------------------------------------------------------------------------------------------------
