@@ -726,23 +726,39 @@ def test_vae_decode_full_size_vs_oracle_whole_image():
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def sdxl_full_truth(sdxl_unet_bf16):
-    """fp32 CPU oracle on the bf16-representable weights of the module fixture: eps of the first Euler step (one UNet
-    forward at batch 2 = [uncond; cond]), the latents after two Euler+CFG steps (`S.sdxl_generate_latents` unrolled so
-    that the first forward is shared), and the bf16 oracle forward.  Three CPU forwards of 13.5 TFLOP each."""
+    """fp32 CPU oracle of the WHOLE de-tokenizer at real size on bf16-representable weights: conditioning through the
+    adapter path (ViT-G of the all-zeros image, ResamplerXLV2 on [feature; negative]), eps of the first Euler step (one UNet
+    forward at batch 2 = [uncond; cond]), the latents after two Euler+CFG steps (`S.sdxl_generate_latents` unrolled so that the
+    first forward is shared), their VAE decode to the 1024^2 uint8 image, and the bf16 oracle forward.  Three CPU UNet
+    forwards of 13.5 TFLOP each + 4 TFLOP of ViT + 10.5 TFLOP of VAE."""
     import time
     import sdxl_oracle as S
     c = S.SDXL_BASE_UNET
     wd = {k: v.detach().float().cpu() for k, v in sdxl_unet_bf16.state_dict().items()}
-    inp = dict(noise=synth.normal_like(71, (1, 4, 128, 128), 1.0), ctx_pos=synth.normal_like(72, (1, 64, 2048), 1.0),
-               ctx_neg=synth.normal_like(73, (1, 64, 2048), 1.0), pooled_pos=synth.normal_like(74, (1, 1280), 1.0),
-               pooled_neg=synth.normal_like(75, (1, 1280), 1.0))
-    inp = {k: v.to(torch.bfloat16).float() for k, v in inp.items()}            # both sides see bf16-representable inputs
+    bfr = lambda d: {k: v.to(torch.bfloat16).float() for k, v in d.items()}      # noqa: E731  bf16-representable fp32 tensors
+    # conditioning as SDXLAdapter.get_image_embeds produces it at REAL size (adapter_modules.py:387-428): the regressed
+    # feature [1, 256, 4096] and the feature of an all-zeros image (whole ViT-G, 48 blocks) through ResamplerXLV2 together
+    xl_cfg = dict(dim=1024, depth=4, dim_head=64, heads=16, num_queries=64, embedding_dim=4096, output1_dim=768,
+                  output2_dim=1280, ff_mult=4)
+    xl_wd = bfr(synth.resampler_xlv2_weights(41, **xl_cfg))
+    vit_wd = bfr(synth.vit_weights(33, 1664, 48, 16, 8192, 14, 4096, 256))
+    vae_wd = bfr(S.synth_weights(S.vae_decoder_shapes(S.SDXL_BASE_VAE), 7))
+    feat = synth.normal_like(76, (1, 256, 4096), 1.0).to(torch.bfloat16).float()
+    t0 = time.time()
+    with torch.no_grad():
+        feat_neg = O.vit_forward(vit_wd, torch.zeros(1, 3, 448, 448), width=1664, layers=48, heads=16, patch=14, out_dim=4096,
+                                 n_queries=256)
+        ctx_pos, ctx_neg, pooled_pos, pooled_neg = S.adapter_image_embeds(xl_wd, xl_cfg, feat, feat_neg)
+    inp = dict(noise=synth.normal_like(71, (1, 4, 128, 128), 1.0).to(torch.bfloat16).float(), ctx_pos=ctx_pos, ctx_neg=ctx_neg,
+               pooled_pos=pooled_pos, pooled_neg=pooled_neg)
     ts, sig, init = S.euler_schedule(2)
     ids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2, dtype=torch.float32)
     ctx = torch.cat([inp["ctx_neg"], inp["ctx_pos"]], 0)
     pooled = torch.cat([inp["pooled_neg"], inp["pooled_pos"]], 0)
     x = inp["noise"] * init
-    out = dict(inp=inp, ts=ts, sig=sig, init=init, ids=ids, ctx=ctx, pooled=pooled)
+    out = dict(inp=inp, ts=ts, sig=sig, init=init, ids=ids, ctx=ctx, pooled=pooled, feat=feat, xl_cfg=xl_cfg, xl_wd=xl_wd,
+               vit_wd=vit_wd, vae_wd=vae_wd)
+    print("CPU oracle: ViT-G (48 blocks) on the all-zeros image + ResamplerXLV2: %.1f s" % (time.time() - t0))
     t0 = time.time()
     with torch.no_grad():
         xin0 = torch.cat([x, x], 0) / math.sqrt(sig[0] ** 2 + 1.0)
@@ -756,6 +772,9 @@ def sdxl_full_truth(sdxl_unet_bf16):
         xin1 = torch.cat([x, x], 0) / math.sqrt(sig[1] ** 2 + 1.0)
         e_neg, e_pos = S.unet_forward(wd, c, xin1, float(ts[1]), ctx, pooled, ids).chunk(2)
         out["x2"] = x + (e_neg + 7.5 * (e_pos - e_neg)) * (sig[2] - sig[1])
+        t2 = time.time()
+        out["image_u8"] = S.postprocess(S.vae_decode(vae_wd, S.SDXL_BASE_VAE, out["x2"]))[0]      # [1024, 1024, 3] uint8
+        out["t_vae"] = time.time() - t2
         t2 = time.time()
         bf = torch.bfloat16
         wbf = {k: v.to(bf) for k, v in wd.items()}
@@ -788,7 +807,40 @@ def test_sdxl_unet_assembled_full_size_fp32(sdxl_unet_bf16, sdxl_full_truth):
     e2 = rel(x2, T["x2"])
     print("two Euler + CFG steps (pipeline, fp32) vs oracle latents: rel %.3e" % e2)
     assert e2 < 1e-3
-    del m32, pipe
+    # ---- the whole de-tokenizer through the reference API surface (adapter_modules.py:430-468): SDXLAdapter.generate from
+    # the regressed feature — negative branch = ViT-G (48 blocks) of an all-zeros image, ResamplerXLV2, 2 Euler + CFG steps,
+    # VAE decode, uint8 image — against the oracle chain
+    from seedstory import _lib
+    from seedstory.diffusion import AutoencoderKL
+    from src.models.discrete_models import DiscreteModleIdentity
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    from src.models_ipa.adapter_modules import SDXLAdapter
+    from src.models_ipa.resampler import ResamplerXLV2
+    rs = ResamplerXLV2(**T["xl_cfg"])
+    assert not any(rs.load_state_dict(T["xl_wd"], strict=False))
+    vit = VisionTransformerWithAttnPool(image_size=448, patch_size=14, width=1664, layers=48, heads=16, mlp_ratio=4.9231,
+                                        n_queries=256, output_dim=4096)
+    assert not any(vit.load_state_dict(T["vit_wd"], strict=False))
+    vae = AutoencoderKL()
+    assert not any(vae.load_state_dict(T["vae_wd"], strict=False))
+    adapter = SDXLAdapter.from_pretrained(unet=m32, resampler=rs).to(DEV).eval()
+    adapter.init_pipe(vae=vae.to(DEV), scheduler=EulerDiscreteScheduler(), visual_encoder=vit, image_transform=None,
+                      discrete_model=DiscreteModleIdentity(), dtype=torch.float32, device=DEV)
+    got = adapter.get_image_embeds(image_embeds=T["feat"].to(DEV))
+    for a_, k_ in zip(got, ("ctx_pos", "ctx_neg", "pooled_pos", "pooled_neg")):
+        assert rel(a_, i[k_]) < 1e-4, k_
+    lat = adapter.generate(image_embeds=T["feat"].to(DEV), num_inference_steps=2, latents=i["noise"].to(DEV), output_type="latent")
+    e3 = rel(lat, T["x2"])
+    _lib.set_tuning("vae_fp32", 1)
+    try:
+        img = adapter.generate(image_embeds=T["feat"].to(DEV), num_inference_steps=2, latents=i["noise"].to(DEV), output_type="pt")
+    finally:
+        _lib.set_tuning("vae_fp32", 0)
+    d = (img.cpu().int() - T["image_u8"].int()).abs()
+    print("SDXLAdapter.generate at real size (feature -> ViT-G negative + ResamplerXLV2 -> 2 Euler + CFG steps -> VAE -> uint8), fp32 vs "
+          "the oracle chain: latents rel %.3e | image uint8 max dev %d, pixels differing %.3f%%" % (e3, int(d.max()), 100.0 * float((d > 0).float().mean())))
+    assert e3 < 1e-3 and img.shape == (1024, 1024, 3) and int(d.max()) <= 2
+    del m32, pipe, adapter, vit, vae
     torch.cuda.empty_cache()
 
 
