@@ -612,3 +612,20 @@ def test_llm_generate_assembles_block_and_sequential_runs_identically(monkeypatc
     seq = a[0][0]
     assert seq[:4] == [1, 40, 41, 42] and seq[4:7] == [60, 61, img[0]] and seq[7:7 + 65] == img[1:] and len(seq) == 4 + 120
     assert a[2] == 4 + 119 and len(a[3]) == 4 + 119            # everything but the last generated token is cached
+
+
+def test_splitk_plan_and_bench_slot_groups():
+    """Host-only logic of round 3: (1) the split-K plan of the small-M LLaMA projections (ss_gemm_splitk_workspace_bytes is
+    pure host code: S slices of M x N fp32; 0 = the regular tiles) — it splits where the column count leaves most CUs
+    idle (N = 4096) and nowhere else; (2) bench.py's decode groups for more than 4 stories per GPU."""
+    from seedstory import _lib
+    f = _lib.lib().ss_gemm_splitk_workspace_bytes
+    H, I = 4096, 11008
+    assert f(264, H, H) == 3 * 264 * H * 4 and f(264, H, I) == 3 * 264 * H * 4            # 192 workgroups of 128x64 -> 3 K ranges
+    assert f(460, H, H) == 2 * 460 * H * 4 and f(512, H, I) == 2 * 512 * H * 4            # 256 workgroups -> 2 K ranges
+    assert f(264, 3 * H, H) == 0 and f(264, 2 * I, H) == 0                                # >= 256 workgroups of 128x128 already
+    assert f(128, H, H) == 0 and f(66, H, I) == 0 and f(513, H, H) == 0 and f(1024, H, I) == 0   # outside 128 < M <= 512
+    assert f(264, H, 512) == 0 and f(264, 100, H) == 0                                    # short K / ragged N: regular path
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.slot_groups(n) for n in (1, 2, 3, 4, 6, 8)] == [[1], [2], [3], [4], [3, 3], [4, 4]]
