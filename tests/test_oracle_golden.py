@@ -222,3 +222,33 @@ def test_greedy_loop_pinned_on_hf_generate():
         assert gen == g[tag + ".generate_ids"].tolist()
         assert rel(hid, g[tag + ".hidden"]) < 2e-6
     assert g["eos.generate_ids"].tolist()[-1] == meta["eos_case_id"] and len(g["eos.generate_ids"]) < meta["MAX_NEW"]
+
+
+def test_full_dimension_generate_fp32():
+    """``ContinuousLVLM.generate`` semantics at hidden 4096 / 32 heads / inter 11008 / vocab 32066 (2 layers) with the
+    full-size resamplers: the oracle reproduces the ids, the 64 regressor input rows and ``img_gen_feat`` that the REAL
+    reference modules produced (oracle/make_golden_full.py), fp32, 2e-6.  ~1.5 min and 6 GB on 8 cores."""
+    g, meta = _full()
+    d, gen = meta["LLAMA"], meta["GEN"]
+    E = d["hidden"]
+    lo, hi = meta["IMG_IDS"]
+    img_ids = list(range(lo, hi + 1))
+    wd = synth.llama_weights(gen["seed"], d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    wd.update(synth.resampler_weights(meta["RES_IN"]["seed"], "input_resampler.", meta["RES_IN"]["grid"], E))
+    wd.update(synth.resampler_weights(meta["RES_OUT"]["seed"], "output_resampler.", meta["RES_OUT"]["grid"], E))
+    n_text = gen["n_text"]
+    prompt = [1] + synth.randint(50, (n_text,), 3, 32000).tolist() + [img_ids[0]] + img_ids[1:65] + [img_ids[-1]]
+    input_ids = torch.tensor([prompt])
+    mask = torch.zeros_like(input_ids, dtype=torch.bool)
+    mask[0, n_text + 2:n_text + 2 + 64] = True
+    image_embeds = synth.normal_like(51, (1, 256, E), 1.0)
+    forced = synth.randint(52, (6,), 3, 32000).tolist() + [img_ids[0]]
+    dims = O.LlamaDims(d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    with torch.no_grad():
+        out = O.lvlm_generate(wd, dims, input_ids, image_embeds, torch.tensor([True]), mask, img_ids, max_new_tokens=gen["max_new"],
+                              forced=forced, n_heads_resampler=32)
+    ids = out["generate_ids"]
+    assert ids == g["gen_f32.generate_ids"].tolist()
+    e = max(i for i, t in enumerate(ids) if t == img_ids[-1])
+    assert rel(_rows(out["hidden"][e - 64:e], gen["hidden_stride"]), g["gen_f32.feed.rows"]) < 2e-6
+    assert rel(_rows(out["img_gen_feat"], gen["feat_stride"]), g["gen_f32.img_gen_feat.rows"]) < 2e-6
