@@ -321,6 +321,17 @@ def cpu_baseline(with_sdxl=True, diffusion_steps=30, budget_s=240.0):
                       " (resamplers excluded, < 0.1 %% of the step; wall time of this sample %.0fs)" % (time.perf_counter() - t_start)}
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio when the first communicator comes up; flushed only at exit it would
+    land BEHIND the JSON line in a redirected stdout.  Flushing C stdio right after the first collective keeps the JSON
+    line the last line of the output."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def slot_groups(spg):
     """Stories per GPU -> sizes of the lock-step decode groups (an engine sweeps the weights for <= 4 slots)."""
     n = (spg + 3) // 4
@@ -492,6 +503,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1 or force_dist:
             dist.barrier()
+            flush_c_stdio()
         torch.cuda.synchronize()
 
     engs, shared = build_engines(device, dtype, SPG)
@@ -791,6 +803,10 @@ def main():
             _tt.save_table(args.save_tune_table, note="written by bench.py")
         print(json.dumps(out))
     if world > 1 or force_dist:
+        # rank 0 spends another ~30 s on the roofline section after the timed region: every rank waits for it here, so that
+        # the communicators are torn down together (a rank that destroys its group while rank 0 still owns live
+        # communicators can leave rank 0 hanging at exit)
+        dist.barrier()
         dist.destroy_process_group()
 
 

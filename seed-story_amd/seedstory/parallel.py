@@ -343,6 +343,8 @@ def bench_slot_partition(args, rank, world, device, dtype, bm):
     torch.cuda.synchronize()
     dist.barrier()
     dt_s = max_over_ranks(time.perf_counter() - t0, "cpu" if gloo else device)
+    if hasattr(bm, "flush_c_stdio"):
+        bm.flush_c_stdio()          # RCCL's version banner (C stdio) goes out before the JSON line, not behind it at exit
     if rank == 0:
         spg = args.stories_per_gpu
         out = {"metric": "story-steps/sec (text + 1024x1024 image)", "value": round(args.steps * spg / dt_s, 4),
