@@ -149,6 +149,14 @@ def test_llama_full_width_prefill_continuation_decode(dtype, n_seq):
 _W7B = {}
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _release_big_host_tensors():
+    """The 7B-shaped weight dicts (27 + 13.5 GB of host memory) live for this module only."""
+    yield
+    _W7B.clear()
+    _W.clear()
+
+
 def _llama7b_weights():
     """LLaMA-2-7B-shaped weights (6.74 B parameters): seeded torch generator, fp32 master = the bf16-representable values
     (both sides of every comparison take THESE tensors).  Cached for the module (27 + 13.5 GB of host memory)."""
