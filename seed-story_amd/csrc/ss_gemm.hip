@@ -365,12 +365,22 @@ static int gemm_glds_launch_cfg(const GemmArgs& g, hipStream_t s) {
 template <typename T> int gemm_sp_dispatch_conv(int cfg, const GemmArgs& g, hipStream_t s);
 template <> int gemm_sp_dispatch<float>(int, const GemmArgs&, hipStream_t) { return 1; }
 template <> int gemm_sp_dispatch_conv<float>(int, const GemmArgs&, hipStream_t) { return 1; }
+// one-stream-per-SIMD kernels (ss_gemm_w4.inc): cfg 90-99; same contract (1 = not eligible)
+template <typename T> int gemm_w4_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
+template <typename T> int gemm_w4_dispatch_conv(int cfg, const GemmArgs& g, hipStream_t s);
+template <> int gemm_w4_dispatch<float>(int, const GemmArgs&, hipStream_t) { return 1; }
+template <> int gemm_w4_dispatch_conv<float>(int, const GemmArgs&, hipStream_t) { return 1; }
 
 // cfg ids: 1-3 register-staged, 8/10/15 double-buffered LDS-DMA (any K % 8 == 0, ragged tiles through a zero page),
 // 20-52 software-pipelined / role-split LDS-DMA (ss_gemm_sp.inc; K % 64 == 0) with the double-buffered kernel of the nearest tile
 // as their fallback for ineligible shapes.
 template <typename T>
 static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
+    if (cfg >= 90 && cfg < 100 && Tr<T>::kVec == 8) {   // 4-wave / AGPR-accumulator tiles; ineligible shapes take the 8-wave 256x256 tile
+        const int rc = g.conv_Cin > 0 ? gemm_w4_dispatch_conv<T>(cfg, g, s) : gemm_w4_dispatch<T>(cfg, g, s);
+        if (rc <= 0) return rc;
+        cfg = g.conv_Cin > 0 ? 69 : 60;
+    }
     if (cfg >= 20 && Tr<T>::kVec == 8) {
         const int rc = g.conv_Cin > 0 ? gemm_sp_dispatch_conv<T>(cfg, g, s) : gemm_sp_dispatch<T>(cfg, g, s);
         if (rc <= 0) return rc;
@@ -573,6 +583,7 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     g.rowvec = nullptr; g.rows_per_batch = 1; g.rowvec_ld = 0;
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
     g.swz = tuning_get("gemm_xcd_swizzle", 8);
+    if (tuning_get("gemm_epi_generic", 0)) g.epi |= SS_EPI_INTERNAL_GENERIC;
     if (rowstat_out) {
         // statistics epilogue: only the staged software-pipelined tiles 61..72 have it (ids + 200); 256x256 tiles (60 / 69)
         // and non-staged choices fall to the 160- / 128-wide staged tile of the shape

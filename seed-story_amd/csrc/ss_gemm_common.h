@@ -10,6 +10,7 @@
 // C[m = l&15][n = 4*(l>>4) .. +3]: four consecutive n per row.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "ss_common.h"
 
@@ -104,6 +105,10 @@ template <typename T> __device__ __forceinline__ float gelu_for(float v) {
     else return gelu_erf(v);
 }
 
+// internal epilogue bit (never part of the C ABI's SS_EPI_* set): take the run-time-flag epilogue variant instead of the
+// compile-time one — tuning knob "gemm_epi_generic", for A/B measurements of the specialisation
+constexpr int SS_EPI_INTERNAL_GENERIC = 1 << 30;
+
 struct GemmArgs {
     const void* A; const void* W; void* C; const void* bias; const void* residual;
     int M, N, K;
@@ -188,6 +193,14 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const void* sbase, uint32_
         :
         : "v"(voff), "s"(sbase), "s"(lds_base)
         : "memory");
+}
+
+// a wave-uniform pointer, made PROVABLY uniform (the "s" operand of dma16s): block-id arithmetic that passes through the
+// persistent tile loop is sometimes classified divergent, and the asm then gets a VGPR pair (assembler error)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)(size_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(size_t)(((uint64_t)hi << 32) | lo);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -356,7 +369,11 @@ __device__ __forceinline__ void gemm_epilogue_partial(const GemmArgs& g, f32x4_t
 // before staging (value rounded to T exactly where the direct path rounds it), the residual is added on the coalesced
 // read-back.  Requirements (checked by the caller): the wave's TM x TN sub-tile lies inside [M, N) in N (rows are
 // masked), C / residual 16-byte aligned with ldc / ldr % 8 == 0.
-template <typename T, int FM, int FN, int CR, int EM = 0, bool RSTAT = false>
+// EV (epilogue variant): the per-value options as COMPILE-TIME constants — 1 plain (bias / residual only), 2 +GELU, 3 +rowvec,
+// 4 GEGLU pair; 0 = every option tested at run time per value (any combination).  With run-time flags the per-value stream
+// carries a scalar branch per GELU test and a round/add/round/select per rowvec test even when the option is off: 28 vector
+// instructions per accumulator value on the ff1 GEGLU tile, ~40 % of them for options that are not in use.
+template <typename T, int FM, int FN, int CR, int EM = 0, bool RSTAT = false, int EV = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                      int lane, char* stg) {
     static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
@@ -364,7 +381,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
     constexpr int FPC = CR / 16;                       // M fragments per chunk
     static_assert(CR % 16 == 0 && FM % FPC == 0, "chunk rows");
     const int l15 = lane & 15, grp = lane >> 4;
-    const bool geglu = (g.epi & SS_EPI_GEGLU_PAIR) != 0;
+    const bool geglu = EV == 0 ? (g.epi & SS_EPI_GEGLU_PAIR) != 0 : EV == 4;
+    const bool do_gelu = EV == 0 ? (g.epi & SS_EPI_GELU) != 0 : EV == 2;
+    const bool do_rowvec = EV == 0 ? g.rowvec != nullptr : EV == 3;
     const int M = g.M;
     T* __restrict__ C = (T*)g.C;
     const T* bias = (const T*)g.bias;
@@ -387,7 +406,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
             const int j = c * FPC + jj;
             const int m = m_base + j * 16 + l15;
             float rv[FN][4];
-            if (g.rowvec) {
+            if (do_rowvec) {
                 const int mm = m < M ? m : M - 1;
                 const T* rp = (const T*)g.rowvec + (int64_t)(mm / g.rows_per_batch) * g.rowvec_ld + n_base + grp * 4;
 #pragma unroll
@@ -406,9 +425,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                     if constexpr (EM == 1) t *= sa * swv[i][r];
                     if constexpr (EM == 2) t = fmaf(t, sa, sh * swv[i][r]);
                     t += bv[i][r];
-                    if (g.epi & SS_EPI_GELU) t = gelu_for<T>(Tr<T>::rnd(t));
+                    if (do_gelu) t = gelu_for<T>(Tr<T>::rnd(t));
                     v[r] = Tr<T>::rnd(t);
-                    if (g.rowvec) v[r] = Tr<T>::rnd(v[r] + rv[i][r]);
+                    if (do_rowvec) v[r] = Tr<T>::rnd(v[r] + rv[i][r]);
                 }
                 if (geglu) {
                     const float o0 = v[0] * Tr<T>::rnd(gelu_for<T>(v[1])), o1 = v[2] * Tr<T>::rnd(gelu_for<T>(v[3]));
