@@ -452,9 +452,12 @@ int ss_conv3x3(const void* x, const void* w, void* y, int64_t batch, int64_t H, 
                int64_t Cout, int64_t stride, int64_t upsample2x, const void* bias, const void* rowvec,
                int64_t rowvec_stride, const void* residual, int dtype, void* stream);
 
-/* nn.GroupNorm over NHWC (+ optional fused SiLU): statistics per (batch, group) accumulated with fp64 atomics (the
- * result does not depend on the order the partial sums land in: two runs agree); stats_ws = batch*groups*2 DOUBLES
- * (16 * batch * groups bytes) of scratch. */
+/* nn.GroupNorm over NHWC (+ optional fused SiLU) — replaces diffusers' ResnetBlock2D.norm1/norm2, Transformer2DModel.norm,
+ * UNet conv_norm_out and the VAE decoder's norms (reference call site: src/models_ipa/adapter_modules.py:455-466 through
+ * the diffusers UNet / AutoencoderKL).  Statistics per (batch, group) are reduced in a FIXED order (block partials in fp64,
+ * folded by a second pass in block order): two runs on the same input give the same bits.  stats_ws must hold
+ * ss_groupnorm_workspace_bytes(batch, hw, channels, groups, dtype) bytes (final sums + block partials). */
+size_t ss_groupnorm_workspace_bytes(int64_t batch, int64_t hw, int64_t channels, int64_t groups, int dtype);
 int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch,
                  int64_t hw, int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream);
 

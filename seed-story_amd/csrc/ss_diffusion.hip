@@ -11,10 +11,15 @@ __device__ __forceinline__ float silu_d(float g) { return g / (1.0f + expf(-g));
 __device__ __forceinline__ float gelu_d(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // =====================================================================================
-// GroupNorm over NHWC: statistics per (batch, group) of H*W x (C/G) elements.
-//   pass 1: partial sum / sum-of-squares per block -> fp64 atomics into stats[b][g][2] (fp64 so that the result does not
-//           depend on the order the atomics land in: two runs of the same forward agree, as the reference's do)
+// GroupNorm over NHWC: statistics per (batch, group) of H*W x (C/G) elements, DETERMINISTIC (round 4: no atomics).
+//   pass 1: every block reduces its rows to per-channel (sum, sum of squares) in a fixed order (thread-sequential over its
+//           rows, then a fixed-order fold over the row lanes through LDS), folds the channels of a group in channel order
+//           in fp64 and writes its partial to part[b][block][g][2]
+//   pass 1b: one block per image sums the block partials in block order (fixed-size slices, slices folded in order)
+//           -> stats[b][g][2] (fp64: E[x^2] - mean^2 without cancellation)
 //   pass 2: y = (x - mean) * rstd * gamma[c] + beta[c]  (+ SiLU), rounded once to T
+// Two runs on the same input give the same bits whatever the dispatch order (rounds 2-3 used fp64 atomics: order-dependent in
+// the last bit, which a 70-block UNet amplified to a 2e-2 difference between two runs when the sums were fp32).
 // (torch GroupNorm computes in fp32 and rounds the result; SiLU then rounds again.)
 // =====================================================================================
 // fast sigmoid-linear unit on the hardware transcendentals: x * rcp(1 + exp2(-x * log2 e))
@@ -28,64 +33,96 @@ __device__ __forceinline__ float silu_fast(float g) {
 // HBM rate instead of being bound by per-element integer divisions and LDS atomics.
 //   thread t of a block: pack p = pc + t % cw, first row r0 + t / cw, row stride 256 / cw   (cw = packs per chunk)
 template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ stats,
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ part,
                                                               int HW, int C, int G, int rows_per_block) {
     constexpr int V = Tr<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* sh = reinterpret_cast<double*>(smem_raw);  // [G][2]
+    float* red = reinterpret_cast<float*>(smem_raw);   // [256][2 V]: per-thread channel sums of the current pack chunk
+    float* chs = red + 256 * 2 * V;                     // [C][2]: this block's per-channel (sum, sum of squares)
     const int b = blockIdx.y;
     const int cg = C / G, ppr = C / V;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(HW, r0 + rows_per_block);
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.0;
-    __syncthreads();
     const T* xb = x + ((int64_t)b * HW) * C;
     for (int pc = 0; pc < ppr; pc += 256) {
         const int cw = min(256, ppr - pc);
         const int rip = 256 / cw;                      // rows in flight per block pass
         const int ry = threadIdx.x / cw, p = pc + threadIdx.x % cw;
-        if (ry >= rip) continue;
+        const bool active = ry < rip;
         float s1[V], s2[V];                            // per-channel partial sums of this thread's pack
 #pragma unroll
         for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-        const T* xp = xb + (int64_t)p * V;
-        int r = r0 + ry;
-        for (; r + rip < r1; r += 2 * rip) {           // two independent loads in flight
-            float f[V], h[V];
-            const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
-            unpack<T>(u0, f);
-            unpack<T>(u1, h);
+        if (active) {
+            const T* xp = xb + (int64_t)p * V;
+            int r = r0 + ry;
+            for (; r + rip < r1; r += 2 * rip) {           // two independent loads in flight
+                float f[V], h[V];
+                const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
+                unpack<T>(u0, f);
+                unpack<T>(u1, h);
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]);
-                s1[j] += h[j]; s2[j] = fmaf(h[j], h[j], s2[j]);
+                for (int j = 0; j < V; ++j) {
+                    s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]);
+                    s1[j] += h[j]; s2[j] = fmaf(h[j], h[j], s2[j]);
+                }
             }
-        }
-        if (r < r1) {
-            float f[V];
-            unpack<T>(ld16(xp + (int64_t)r * C), f);
+            if (r < r1) {
+                float f[V];
+                unpack<T>(ld16(xp + (int64_t)r * C), f);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
-        }
-        // fold the pack's channels into their groups (consecutive channels of one group are summed first)
-        int g = (p * V) / cg;
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int gj = (p * V + j) / cg;
-            if (gj != g) {
-                unsafeAtomicAdd(sh + 2 * g, (double)a1);
-                unsafeAtomicAdd(sh + 2 * g + 1, (double)a2);
-                g = gj; a1 = 0.f; a2 = 0.f;
+                for (int j = 0; j < V; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
             }
-            a1 += s1[j];
-            a2 += s2[j];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { red[threadIdx.x * 2 * V + 2 * j] = s1[j]; red[threadIdx.x * 2 * V + 2 * j + 1] = s2[j]; }
         }
-        unsafeAtomicAdd(sh + 2 * g, (double)a1);
-        unsafeAtomicAdd(sh + 2 * g + 1, (double)a2);
+        __syncthreads();
+        if (active && ry == 0) {       // fold the row lanes of this pack in lane order
+            for (int k = 1; k < rip; ++k) {
+                const float* o = red + (k * cw + (int)threadIdx.x) * 2 * V;
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s1[j] += o[2 * j]; s2[j] += o[2 * j + 1]; }
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) { chs[(p * V + j) * 2] = s1[j]; chs[(p * V + j) * 2 + 1] = s2[j]; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256) unsafeAtomicAdd(stats + (int64_t)b * G * 2 + i, sh[i]);
+    double* out = part + (((int64_t)b * gridDim.x + blockIdx.x) * G) * 2;
+    for (int g = threadIdx.x; g < G; g += 256) {       // channels of a group in channel order, fp64
+        double a1 = 0.0, a2 = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { a1 += (double)chs[2 * c]; a2 += (double)chs[2 * c + 1]; }
+        out[2 * g] = a1;
+        out[2 * g + 1] = a2;
+    }
+}
+
+// stats[b][g] = sum over the blocks of image b, in block order: thread (slice, g) sums a contiguous slice of blocks, the slices
+// are folded in slice order
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats,
+                                                                 int nblk, int G) {
+    __shared__ double sl[256 * 2];
+    const int b = blockIdx.x;
+    const int gw = G < 256 ? G : 256;                   // groups handled per sweep
+    const int ns = 256 / gw;                            // slices
+    for (int g0 = 0; g0 < G; g0 += gw) {
+        const int g = g0 + (int)threadIdx.x % gw, sidx = (int)threadIdx.x / gw;
+        double a1 = 0.0, a2 = 0.0;
+        if (sidx < ns && g < G) {
+            const int per = (nblk + ns - 1) / ns;
+            const int k0 = sidx * per, k1 = min(nblk, k0 + per);
+            const double* pp = part + ((int64_t)b * nblk * G + g) * 2;
+            for (int k = k0; k < k1; ++k) { a1 += pp[(int64_t)k * G * 2]; a2 += pp[(int64_t)k * G * 2 + 1]; }
+        }
+        sl[threadIdx.x * 2] = a1;
+        sl[threadIdx.x * 2 + 1] = a2;
+        __syncthreads();
+        if (sidx == 0 && g < G) {
+            for (int k = 1; k < ns; ++k) { a1 += sl[(k * gw + (int)threadIdx.x) * 2]; a2 += sl[(k * gw + (int)threadIdx.x) * 2 + 1]; }
+            stats[((int64_t)b * G + g) * 2] = a1;
+            stats[((int64_t)b * G + g) * 2 + 1] = a2;
+        }
+        __syncthreads();
+    }
 }
 
 template <typename T>
@@ -143,22 +180,39 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     }
 }
 
+static int groupnorm_rows_per_block(int64_t B, int64_t HW, int64_t C, size_t elem) {
+    // ~128 KiB of activations per block, at least enough blocks to fill the chip several times
+    int rows_per_block = (int)((128 * 1024) / (C * elem));
+    if (rows_per_block < 16) rows_per_block = 16;
+    while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 2048) rows_per_block /= 2;
+    if (rows_per_block > HW) rows_per_block = (int)HW;
+    return rows_per_block;
+}
+
+// workspace = [B][G][2] final sums + [B][blocks][G][2] block partials, doubles
+size_t groupnorm_workspace_bytes(int64_t B, int64_t HW, int64_t C, int64_t G, int dtype) {
+    if (B * HW == 0) return 0;
+    const int rpb = groupnorm_rows_per_block(B, HW, C, dtype_size(dtype));
+    return (size_t)B * G * 2 * sizeof(double) * (1 + (size_t)cdiv(HW, rpb));
+}
+
 template <typename T>
-int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, double* stats, int64_t B, int64_t HW,
+int groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, double* ws, int64_t B, int64_t HW,
                      int64_t C, int64_t G, float eps, int silu, hipStream_t s) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(C % G == 0 && C % V == 0, "groupnorm: C=%lld G=%lld unsupported", (long long)C, (long long)G);
     if (B * HW == 0) return SS_OK;
-    SS_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(double), s));
-    // ~128 KiB of activations per block, at least enough blocks to fill the chip several times
-    int rows_per_block = (int)((128 * 1024) / (C * sizeof(T)));
-    if (rows_per_block < 16) rows_per_block = 16;
-    while (rows_per_block > 16 && B * cdiv(HW, rows_per_block) < 2048) rows_per_block /= 2;
-    if (rows_per_block > HW) rows_per_block = (int)HW;
+    const int rows_per_block = groupnorm_rows_per_block(B, HW, C, sizeof(T));
     dim3 grid((unsigned)cdiv(HW, rows_per_block), (unsigned)B);
-    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), (size_t)G * 2 * sizeof(double), s, (const T*)x, stats,
-                       (int)HW, (int)C, (int)G, rows_per_block);
+    double* stats = ws;
+    double* part = ws + (size_t)B * G * 2;
+    const size_t lds = (size_t)256 * 2 * V * sizeof(float) + (size_t)C * 2 * sizeof(float);
+    SS_REQUIRE(lds <= 64 * 1024, "groupnorm: C=%lld too wide", (long long)C);
+    hipLaunchKernelGGL(groupnorm_stats_kernel<T>, grid, dim3(256), lds, s, (const T*)x, part, (int)HW, (int)C, (int)G,
+                       rows_per_block);
     SS_LAUNCH_CHECK("groupnorm_stats");
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((unsigned)B), dim3(256), 0, s, (const double*)part, stats, (int)grid.x, (int)G);
+    SS_LAUNCH_CHECK("groupnorm_finalize");
     hipLaunchKernelGGL(groupnorm_apply_kernel<T>, grid, dim3(256), 0, s, (const T*)x, stats, (const T*)gamma,
                        (const T*)beta, (T*)y, (int)HW, (int)C, (int)G, eps, silu, rows_per_block);
     SS_LAUNCH_CHECK("groupnorm_apply");
@@ -399,6 +453,10 @@ int image_to_u8_launch(const void* in, void* out, int64_t pixels, int64_t Cpad, 
 using namespace ss;
 
 extern "C" {
+
+size_t ss_groupnorm_workspace_bytes(int64_t batch, int64_t hw, int64_t channels, int64_t groups, int dtype) {
+    return ss::groupnorm_workspace_bytes(batch, hw, channels, groups, dtype);
+}
 
 int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch, int64_t hw,
                  int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream) {

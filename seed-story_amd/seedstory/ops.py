@@ -313,7 +313,8 @@ def groupnorm(x, gamma, beta, B, groups, eps, silu=False):
     C = x.shape[-1]
     HW = x.shape[0] // B
     y = torch.empty_like(x)
-    ws = torch.empty(B * groups * 2, dtype=torch.float64, device=x.device)
+    nb = int(lib().ss_groupnorm_workspace_bytes(B, HW, C, groups, dt(x)))      # final sums + deterministic block partials
+    ws = torch.empty(max(nb // 8, 1), dtype=torch.float64, device=x.device)
     check(lib().ss_groupnorm(p(x), p(gamma), p(beta), p(y), p(ws), B, HW, C, groups, eps, int(silu), dt(x), stream()),
           "ss_groupnorm")
     return y

@@ -883,7 +883,9 @@ def test_sdxl_unet_assembled_full_size_bf16(sdxl_unet_bf16, sdxl_full_truth):
         _lib.set_tuning("unet_graph", 1)
     eg = rel(xg, xe)
     print("4-step render, hipGraph replay vs eager: rel %.3e" % eg)
-    assert eg < 2e-2      # GroupNorm statistics are fp64 atomics: order-dependent in the last bit, amplified by 70 blocks
+    # round 4: GroupNorm statistics are a fixed-order two-stage reduction (no atomics): nothing on the forward depends on the
+    # dispatch order any more, so replay and eager agree bit for bit (rounds 2-3: fp64 atomics, gate 2e-2)
+    assert torch.equal(xg, xe)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

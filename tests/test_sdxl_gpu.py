@@ -128,6 +128,23 @@ def test_groupnorm_silu(B, C, H, W, G, dtype):
         assert rel(nchw(y.cpu(), B, H, W), ref) < (2e-5 if dtype == torch.float32 else 6e-3)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(8, 1280, 32, 32), (2, 2560, 32, 32), (2, 320, 128, 128)])
+def test_groupnorm_deterministic_full_size(B, C, H, W):
+    """UNet-sized GroupNorm (hundreds of blocks per image, two pack chunks at C = 2560): the two-stage fixed-order statistics
+    make repeated runs bit-identical (fp64 atomics, rounds 2-3, were order-dependent in the last bit), and the result still
+    matches torch's fp32 group_norm at bf16 resolution."""
+    from seedstory import ops
+    x = synth.normal_like(31, (B, C, H, W), 2.0, 0.7, dtype=torch.bfloat16)
+    g = synth.normal_like(32, (C,), 0.1, 1.0, dtype=torch.bfloat16)
+    b = synth.normal_like(33, (C,), 0.1, dtype=torch.bfloat16)
+    xd, gd, bd = nhwc(x).to(DEV), g.to(DEV), b.to(DEV)
+    ys = [ops.groupnorm(xd, gd, bd, B, 32, 1e-5, silu=True) for _ in range(4)]
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+    ref = F.silu(F.group_norm(x.float(), 32, g.float(), b.float(), 1e-5))
+    assert rel(nchw(ys[0].cpu(), B, H, W), ref) < 6e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_small_diffusion_ops(dtype):
     from seedstory import ops

@@ -28,6 +28,8 @@ def parse(spec):
         if item.startswith("knob:"):
             _, k, v = item.split(":")
             knobs.append((k, int(v)))
+        elif item.startswith("lnfold:"):
+            knobs.append(("__lnfold__", int(item.split(":")[1])))
         else:
             shape, cs = item.split(":")
             M, N, K = [int(v) for v in shape.split(",")]
@@ -44,11 +46,17 @@ all_knobs = {k for _, _, ks in variants for k, _ in ks}
 def apply(entries, knobs):
     tune.import_table([table0[k] for k in all_keys if k in table0])       # restore the shipped choices
     for k in all_knobs:
-        _lib.set_tuning(k, 0)
+        if k != "__lnfold__":
+            _lib.set_tuning(k, 0)
     if entries:
         tune.import_table(entries)
+    lnf = 0
     for k, v in knobs:
-        _lib.set_tuning(k, v)
+        if k == "__lnfold__":
+            lnf = v
+        else:
+            _lib.set_tuning(k, v)
+    unet.enable_lnfold(bool(lnf))
 
 
 def fwd_ms(n):
