@@ -461,6 +461,24 @@ size_t ss_groupnorm_workspace_bytes(int64_t batch, int64_t hw, int64_t channels,
 int ss_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* stats_ws, int64_t batch,
                  int64_t hw, int64_t channels, int64_t groups, float eps, int fuse_silu, int dtype, void* stream);
 
+/* ---- loss heads of the training-side forward (forward only) ------------------------------------------
+ * Deterministic (fixed-order reductions, no atomics); 16-bit dtypes round where the reference's torch graph rounds.
+ *
+ * ss_cross_entropy_rows — the token loss of LlamaForCausalLM.forward(labels=...)
+ *   (src/models_clm/modeling_llama_xformer.py:761-772: CrossEntropyLoss over logits[..., :-1, :] / labels[..., 1:]):
+ *   row_loss[r] = -log_softmax(logits[r, :vocab])[labels[r]], row_valid[r] = 1; labels[r] == ignore_index -> 0 / 0.
+ *   The caller passes the already shifted rows (logits row r with the label of position r + 1).
+ * ss_cosine_rows — cosine_loss of src/models_clm/models.py:13-17: row_val[r] = 1 - <rec_r/|rec_r|, target_r/|target_r|>.
+ * ss_masked_mean — out2[0] = sum(vals * mask) / sum(mask) (mask NULL: plain mean), out2[1] = the denominator;
+ *   workspace = ss_loss_workspace_bytes(n).
+ * ss_mse — F.mse_loss(a.float(), b.float(), reduction="mean") of src/models_ipa/adapter_modules.py:339 -> out2[0]. */
+size_t ss_loss_workspace_bytes(int64_t n);
+int ss_cross_entropy_rows(const void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t vocab,
+                          int64_t ignore_index, float* row_loss, float* row_valid, int dtype, void* stream);
+int ss_cosine_rows(const void* rec, const void* target, int64_t rows, int64_t dim, float* row_val, int dtype, void* stream);
+int ss_masked_mean(const float* vals, const float* mask, int64_t n, void* workspace, float* out2, void* stream);
+int ss_mse(const void* a, const void* b, int64_t n, void* workspace, float* out2, int dtype, void* stream);
+
 /* diffusers GEGLU: in [rows, 2d] = [value | gate] -> out[r,i] = value * gelu_erf(gate). */
 int ss_geglu(const void* in, void* out, int64_t rows, int64_t d, int dtype, void* stream);
 /* y = silu(x) (op 0) | gelu_erf(x) (op 1), element-wise (time-embedding activations). */

@@ -307,6 +307,52 @@ def lvlm_generate(wd: W, dims: LlamaDims, input_ids: Tensor, image_embeds: Optio
             "num_gen_imgs": 1 if eoi else 0, "hidden": hidden, "scores": scores, "past_key_values": kv}
 
 
+def cosine_loss(rec: Tensor, target: Tensor) -> Tensor:
+    """src/models_clm/models.py:13-17."""
+    target = target / target.norm(dim=-1, keepdim=True)
+    rec = rec / rec.norm(dim=-1, keepdim=True)
+    return (1 - (target * rec).sum(-1)).mean()
+
+
+def lvlm_forward(wd: W, dims: LlamaDims, input_ids: Tensor, labels: Tensor, image_embeds: Optional[Tensor],
+                 embeds_gen_mask: Optional[Tensor], embeds_cmp_mask: Optional[Tensor], ids_gen_mask: Optional[Tensor],
+                 ids_cmp_mask: Optional[Tensor], n_heads_resampler: int = 32, lm_loss_scale: float = 1.0,
+                 rec_loss_scale: float = 1.0, lora_scaling: float = 2.0):
+    """ContinuousLVLM.forward — src/models_clm/models.py:33-96 (training-side forward, no autograd needed here).
+
+    ``attention_mask`` is not a parameter: the reference hands it to the LLM (:64), whose xformers attention ignores it
+    (modeling_llama_xformer.py:281-295, ``attn_bias=LowerTriangularMask()``; the additive mask of :274 only changes the
+    discarded ``attn_weights``) — every sequence is plain causal attention over all its (padded) rows.  The token loss is
+    CrossEntropyLoss over ``logits[..., :-1, :]`` / ``labels[..., 1:]`` (modeling_llama_xformer.py:761-772).  The
+    placeholder branches for batches without images (:41-47, 58-62, 82-90) multiply random tensors by 0.0: exactly zero."""
+    embed = wd["model.embed_tokens.weight"]
+    input_embeds = embed[input_ids].clone()                               # :36
+    bz, sq, dim = input_embeds.shape
+    has_image = image_embeds is not None
+    has_image_input = has_image and int(embeds_cmp_mask.sum()) > 0
+    has_image_output = has_image and int(embeds_gen_mask.sum()) > 0
+    if has_image_input:
+        lm = resampler_forward(wd, "input_resampler.", image_embeds, n_heads_resampler)      # :40
+        input_embeds[ids_cmp_mask] = lm[embeds_cmp_mask].view(-1, dim)                       # :55
+    pos = torch.arange(sq).unsqueeze(0)
+    logits, last, _ = llama_forward(wd, dims, input_embeds, pos, None, lora_scaling)         # :64-68
+    shift_logits = logits[..., :-1, :].contiguous().view(-1, dims.vocab)
+    shift_labels = labels[..., 1:].contiguous().view(-1)
+    lm_loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels)                  # CrossEntropyLoss(), ignore -100
+    recon = None
+    if has_image_output:
+        target = image_embeds[embeds_gen_mask]                                               # :74
+        n = target.shape[0]
+        out_embeds = last[ids_gen_mask].view(n, -1, dim)                                     # :76
+        recon = resampler_forward(wd, "output_resampler.", out_embeds, n_heads_resampler)    # :79
+        rec_loss = cosine_loss(recon, target)                                                # :81
+    else:
+        rec_loss = torch.zeros((), dtype=input_embeds.dtype)
+    total = lm_loss_scale * lm_loss + rec_loss_scale * rec_loss                              # :92
+    return {"total_loss": total, "lm_loss": lm_loss, "rec_loss": rec_loss, "recon_image_embeds": recon,
+            "last_hidden_state": last, "logits": logits}
+
+
 # ---- Qwen ViT-G with attention pool ---------------------------------------------------
 
 

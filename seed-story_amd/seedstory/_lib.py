@@ -122,6 +122,11 @@ PROTOTYPES = {
     "ss_vit_forward": (C.c_int, [C.POINTER(VitWeights), vp, vp, i64, vp, sz, C.c_int, vp]),
     "ss_vit_blocks": (C.c_int, [C.POINTER(VitWeights), vp, i64, i64, i64, i64, vp, sz, C.c_int, vp]),
     "ss_conv3x3": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, C.c_int, vp]),
+    "ss_loss_workspace_bytes": (C.c_size_t, [i64]),
+    "ss_cross_entropy_rows": (C.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, C.c_int, vp]),
+    "ss_cosine_rows": (C.c_int, [vp, vp, i64, i64, vp, C.c_int, vp]),
+    "ss_masked_mean": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "ss_mse": (C.c_int, [vp, vp, i64, vp, vp, C.c_int, vp]),
     "ss_groupnorm_workspace_bytes": (C.c_size_t, [i64, i64, i64, i64, C.c_int]),
     "ss_groupnorm": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, C.c_int, C.c_int, vp]),
     "ss_geglu": (C.c_int, [vp, vp, i64, i64, C.c_int, vp]),

@@ -320,6 +320,55 @@ def groupnorm(x, gamma, beta, B, groups, eps, silu=False):
     return y
 
 
+# ---- loss heads of the training-side forward (forward only) ---------------------------------------
+def _mean2(vals, mask):
+    n = vals.numel()
+    ws = torch.empty(max(int(lib().ss_loss_workspace_bytes(n)) // 8, 1), dtype=torch.float64, device=vals.device)
+    out = torch.empty(2, dtype=torch.float32, device=vals.device)
+    check(lib().ss_masked_mean(p(vals), p(mask) if mask is not None else None, n, p(ws), p(out), stream()), "ss_masked_mean")
+    return out
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """CrossEntropyLoss()(logits [R, V], labels [R]) as modeling_llama_xformer.py:769-772 calls it: the mean over the rows whose
+    label is not ``ignore_index`` -> (loss scalar tensor fp32, number of valid rows tensor)."""
+    _req(logits)
+    R, V = logits.shape
+    labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+    assert labels.numel() == R and logits.stride(1) == 1
+    row = torch.empty(R, dtype=torch.float32, device=logits.device)
+    valid = torch.empty(R, dtype=torch.float32, device=logits.device)
+    check(lib().ss_cross_entropy_rows(p(logits), logits.stride(0), p(labels), R, V, ignore_index, p(row), p(valid), dt(logits),
+                                      stream()), "ss_cross_entropy_rows")
+    out = _mean2(row, valid)
+    return out[0], out[1]
+
+
+def cosine_loss(rec, target):
+    """models.py:13-17: (1 - (target/|target| * rec/|rec|).sum(-1)).mean() -> scalar tensor fp32."""
+    _req(rec)
+    _req(target)
+    assert rec.shape == target.shape and rec.dtype == target.dtype
+    dim = rec.shape[-1]
+    r2, t2 = rec.reshape(-1, dim).contiguous(), target.reshape(-1, dim).contiguous()
+    val = torch.empty(r2.shape[0], dtype=torch.float32, device=rec.device)
+    check(lib().ss_cosine_rows(p(r2), p(t2), r2.shape[0], dim, p(val), dt(rec), stream()), "ss_cosine_rows")
+    return _mean2(val, None)[0]
+
+
+def mse_loss(a, b):
+    """F.mse_loss(a.float(), b.float(), reduction='mean') (adapter_modules.py:339) -> scalar tensor fp32."""
+    _req(a)
+    _req(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    a2, b2 = a.contiguous(), b.contiguous()
+    n = a2.numel()
+    ws = torch.empty(max(int(lib().ss_loss_workspace_bytes(n)) // 8, 1), dtype=torch.float64, device=a.device)
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    check(lib().ss_mse(p(a2), p(b2), n, p(ws), p(out), dt(a), stream()), "ss_mse")
+    return out[0]
+
+
 def geglu(x):
     _req(x)
     rows, two_d = x.shape

@@ -205,17 +205,17 @@ class LlamaForCausalLM(nn.Module):
         (lm_head on every row, :759), the grown cache, and — unlike the reference, which can return every layer's input —
         ``hidden_states = (last,)``: the post-final-norm states, the only entry the path reads (models.py:182-197 uses
         ``hidden_states[-1]``).  Side effects as the reference: ``self.past_key_values`` (:778), ``kv_cache_head``
-        (:780-784).  ``labels`` (training loss, :761-772) is outside the inference path."""
-        if labels is not None:
-            raise NotImplementedError("training loss (reference :761-772) is outside the inference hot path")
+        (:780-784).  With ``labels`` or a batch of sequences: `_forward_sequences` (loss :761-772, forward only)."""
         if output_attentions:
             raise NotImplementedError("attention probabilities are never materialised (flash attention)")
         eng = self.engine_for_generation(tuple(getattr(self, "_img_ids", ())))
         dev = eng.device
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids.to(dev))
-        if inputs_embeds.shape[0] != 1:
-            raise ValueError("the story path is batch 1")
+        if labels is not None or inputs_embeds.shape[0] != 1:
+            if past_key_values is not None:
+                raise ValueError("the batched / loss forward takes whole sequences (no past_key_values)")
+            return self._forward_sequences(eng, inputs_embeds.to(dev), labels, position_ids, output_hidden_states, return_dict)
         rows = inputs_embeds[0].to(dev)
         q = rows.shape[0]
         if past_key_values is None:
@@ -243,6 +243,52 @@ class LlamaForCausalLM(nn.Module):
             return (logits, pkv) + ((out.hidden_states,) if output_hidden_states else ())
         return out
 
+
+    def _forward_sequences(self, eng, inputs_embeds, labels, position_ids, output_hidden_states, return_dict):
+        """The training-side call (reference :703-794 with ``labels``; forward only): ``inputs_embeds``
+        [bz, sq, H] are bz independent causal sequences.  ``attention_mask`` plays no role in the outputs — the reference's
+        xformers call ignores it too (``attn_bias=LowerTriangularMask()``, :281-295; the additive mask of :274 only
+        touches ``attn_weights``, which is discarded), so right-padded rows are ordinary tokens whose labels are -100.
+        logits for every row (:759); loss = CrossEntropyLoss over logits[..., :-1, :] / labels[..., 1:] (:761-772), one
+        fixed-order reduction on the device, rounded to the model dtype like torch's."""
+        from seedstory import ops as _ops
+        bz, sq, H = inputs_embeds.shape
+        if sq > eng.max_rows:
+            raise ValueError("sequence length %d exceeds max_prefill_rows=%d" % (sq, eng.max_rows))
+        hid = torch.empty(bz, sq, H, dtype=inputs_embeds.dtype, device=inputs_embeds.device)
+        V = self.lm_head.weight.shape[0]
+        logits = torch.empty(bz, sq, V, dtype=inputs_embeds.dtype, device=inputs_embeds.device)
+        for b in range(bz):
+            eng.reset()
+            pos = None
+            if position_ids is not None:
+                pr = position_ids if position_ids.dim() == 1 or position_ids.shape[0] == 1 else position_ids[b]
+                pos = pr.reshape(-1).to(device=inputs_embeds.device, dtype=torch.int32)
+            hb = eng.prefill(inputs_embeds[b].contiguous(), pos_ids=pos, want_hidden=True)     # [sq, H], post final norm
+            hid[b].copy_(hb)
+            _ops.gemm(hid[b], self.lm_head.weight, out=logits[b])
+        eng.reset()
+        loss = None
+        if labels is not None:
+            labels = labels.to(inputs_embeds.device)
+            if labels.shape != (bz, sq):
+                raise ValueError("labels must be [batch, sequence]")
+            bad = (labels != -100) & ((labels < 0) | (labels >= V))
+            if bool(bad.any()):
+                raise ValueError("label outside [0, vocab) (and not -100)")
+            shift_logits = logits[:, :-1, :].reshape(-1, V).contiguous()
+            shift_labels = labels[:, 1:].reshape(-1)
+            loss, n_valid = _ops.cross_entropy(shift_logits, shift_labels, -100)
+            if float(n_valid) == 0.0:
+                loss = torch.full((), float("nan"), device=loss.device)      # CrossEntropyLoss over no target
+            loss = loss.to(inputs_embeds.dtype)
+        self.past_key_values = None
+        out = CausalLMOutputWithPast(logits=logits, past_key_values=None,
+                                     hidden_states=(hid,) if output_hidden_states else None, loss=loss)
+        if return_dict is False:
+            t = (logits, None) + ((out.hidden_states,) if output_hidden_states else ())
+            return ((loss,) + t) if loss is not None else t
+        return out
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
                                       **kwargs):
@@ -331,6 +377,8 @@ class CausalLMOutputWithPast:
         self.hidden_states, self.attentions = hidden_states, attentions
 
     def __getitem__(self, i):
+        if isinstance(i, str):        # ModelOutput's dict-style access (models.py:69 reads output_lm['loss'])
+            return getattr(self, i)
         return (self.logits, self.past_key_values, self.hidden_states)[i]
 
 

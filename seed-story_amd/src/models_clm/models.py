@@ -6,7 +6,8 @@ reference does — embed + splice image features (:127-135), greedy decode with 
 logits processor (:137-153), slice the 64 last-layer states in front of the last ``</img>``
 (:182-197) and regress them to a 256x4096 ViT-space feature with the output resampler (:205) —
 but every tensor op is a HIP kernel of libseedstory_hip.so and the T-iteration decode loop runs
-from one hipGraph with no per-token host sync.  Training ``forward`` (:33-96) is out of scope.
+from one hipGraph with no per-token host sync.  ``forward`` (:33-96) is the training-side forward WITHOUT autograd:
+losses and the regressed features as the reference computes them, no backward kernels.
 """
 import torch
 from torch import nn
@@ -30,8 +31,53 @@ class ContinuousLVLM(nn.Module):
         self.lm_loss_scale = lm_loss_scale
         self.rec_loss_scale = rec_loss_scale
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("training forward (reference models.py:33-96) is outside the inference hot path")
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask, labels, image_embeds, embeds_gen_mask, embeds_cmp_mask, ids_gen_mask,
+                ids_cmp_mask, return_recon_image_embeds=False):
+        """The training-side forward of the reference (models.py:33-96), FORWARD ONLY (no autograd):
+        splice the input-resampled features of the comprehension images into the embedded batch (:54-56), run the LLM on
+        the bz sequences with the token cross-entropy (:64-69), regress the last-layer states at the generation slots
+        through the output resampler and score them with the cosine loss against the target ViT features (:73-81),
+        ``total = lm_loss_scale * lm + rec_loss_scale * rec`` (:92).  The reference's placeholder branches for batches
+        without images multiply random tensors by 0.0 (:41-47, 58-62, 82-90): here the corresponding terms are exactly 0."""
+        embed = self.llm.get_input_embeddings()
+        dev = embed.weight.device
+        input_ids = input_ids.to(dev)
+        input_embeds = embed(input_ids)                                   # [bz, sq, H]   (:36)
+        bz, sq, dim = input_embeds.shape
+        has_image = image_embeds is not None
+        has_image_input = has_image and int(embeds_cmp_mask.sum().item()) > 0
+        has_image_output = has_image and int(embeds_gen_mask.sum().item()) > 0
+        if has_image:
+            image_embeds = image_embeds.to(dev)
+        if has_image_input:
+            image_embeds_lm = self.input_resampler(image_embeds)          # [Nimg, nq, H]  (:40)
+            sel = image_embeds_lm[embeds_cmp_mask.to(dev)].reshape(-1, dim).contiguous()
+            idx = torch.nonzero(ids_cmp_mask.to(dev).reshape(-1), as_tuple=False).flatten()
+            assert idx.numel() == sel.shape[0], "ids_cmp_mask / embeds_cmp_mask disagree"
+            flat = input_embeds.reshape(-1, dim)
+            ops.scatter_rows_(flat, idx, sel)                             # (:55)
+            input_embeds = flat.view(bz, sq, dim)
+        output_lm = self.llm(attention_mask=attention_mask, inputs_embeds=input_embeds, labels=labels,
+                             output_hidden_states=True, return_dict=True)
+        lm_loss = output_lm['loss']
+        last_hidden_state = output_lm.hidden_states[-1]                   # [bz, sq, H]
+        recon_image_embeds = None
+        if has_image_output:
+            target_embeds = image_embeds[embeds_gen_mask.to(dev)].contiguous()       # [Ngen, 256, 4096]  (:74)
+            num_imgs_for_rec = target_embeds.shape[0]
+            gidx = torch.nonzero(ids_gen_mask.to(dev).reshape(-1), as_tuple=False).flatten()
+            rows = ops.gather_rows(last_hidden_state.reshape(-1, dim).contiguous(), gidx.to(torch.int32))
+            output_image_embeds = rows.view(num_imgs_for_rec, -1, dim)               # (:76)
+            recon_image_embeds = self.output_resampler(output_image_embeds)          # (:79)
+            rec_loss = ops.cosine_loss(recon_image_embeds.contiguous(), target_embeds).to(input_embeds.dtype)   # (:81)
+        else:
+            rec_loss = torch.zeros((), dtype=input_embeds.dtype, device=dev)
+        total_loss = self.lm_loss_scale * lm_loss + self.rec_loss_scale * rec_loss   # (:92)
+        out = {'total_loss': total_loss, 'lm_loss': lm_loss, 'rec_loss': rec_loss}
+        if return_recon_image_embeds and has_image_output:
+            out['recon_image_embeds'] = recon_image_embeds
+        return out
 
     @torch.no_grad()
     def generate(self, tokenizer, prompt=None, input_ids=None, image_embeds=None, embeds_cmp_mask=None,

@@ -35,8 +35,20 @@ class SDXLAdapter(nn.Module):
     def params_to_opt(self):
         return itertools.chain(self.resampler.parameters(), [])
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("training forward (reference adapter_modules.py:330-343) is outside the inference hot path")
+    @torch.no_grad()
+    def forward(self, noisy_latents, timesteps, image_embeds, text_embeds, noise, time_ids):
+        """The training-side forward of the reference (adapter_modules.py:330-343), FORWARD ONLY (no autograd; SURVEY §8
+        row f4): conditioning through the resampler, one UNet call on the noised latents at per-sample ``timesteps``,
+        ``F.mse_loss(noise_pred.float(), noise.float())`` as one fixed-order device reduction."""
+        from seedstory import ops
+        image_embeds, pooled_image_embeds = self.resampler(image_embeds)
+        unet_added_conditions = {"time_ids": time_ids, 'text_embeds': pooled_image_embeds}
+        noise_pred = self.unet(noisy_latents, timesteps, image_embeds, added_cond_kwargs=unet_added_conditions).sample
+        a, b = noise_pred, noise.to(noise_pred.device)
+        if a.dtype != b.dtype:
+            a, b = a.float(), b.float()
+        loss = ops.mse_loss(a.contiguous(), b.contiguous())
+        return {'total_loss': loss, 'noise_pred': noise_pred}
 
     def encode_image_embeds(self, image_embeds):
         return self.resampler(image_embeds)
