@@ -144,8 +144,8 @@ def pack_payload(tensors, device):
     flat = torch.empty(max(total, 16), dtype=torch.uint8, device=device)
     for t, o in zip(tensors, offs):
         n = t.numel() * t.element_size()
-        if n:
-            flat[o:o + n].copy_(t.contiguous().view(-1).view(torch.uint8))
+        if n:      # straight into its place in the flat buffer (t may be a strided view of the KV slab: no staging copy)
+            flat[o:o + n].view(t.dtype).view(t.shape).copy_(t)
     return flat
 
 
@@ -170,7 +170,13 @@ def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu",
     pool = ThreadPoolExecutor(max_workers=1)
     pending = []
     err = []
-    comm = world > 1 or (dist.is_available() and dist.is_initialized())
+    # collectives run on the group this ring was GIVEN: a default group wider than `world` must not be touched
+    comm = world > 1
+    if not comm and dist.is_available() and dist.is_initialized():
+        comm = dist.get_world_size(group) == world
+    if comm:
+        assert dist.get_world_size(group) == world, (dist.get_world_size(group), world)
+    pdev = getattr(backend, "device", None)        # where payload buffers live when `alloc` only describes them (meta tensors)
 
     def render_job(r, meta, tensors):
         try:
@@ -193,12 +199,11 @@ def run_slot_ring(backend, n_rounds, rank, world, group=None, meta_device="cpu",
             meta = header[1:1 + int(header[0])].tolist()
             tensors = backend.alloc(meta)
         if comm and tensors:
-            if rank == owner:
-                flat = pack_payload(tensors, tensors[0].device)
-                if flat.is_cuda:
-                    torch.cuda.current_stream().synchronize()
+            dev_ = tensors[0].device if tensors[0].device.type != "meta" else pdev
+            if rank == owner:       # (stream-ordered behind the MLLM half; RCCL waits on the stream, gloo stages through .cpu())
+                flat = pack_payload(tensors, dev_)
             else:
-                flat = torch.empty(max(_flat_layout(tensors)[1], 16), dtype=torch.uint8, device=tensors[0].device)
+                flat = torch.empty(max(_flat_layout(tensors)[1], 16), dtype=torch.uint8, device=dev_)
             _bcast(flat, owner, group)
             if rank != owner:
                 tensors = unpack_payload(flat, tensors)
@@ -245,18 +250,8 @@ class StoryRingBackend(SlotRingBackend):
         first = sts[0].step == 0
         S = [len(st.ids) for st in sts]
         full = [first or st.evicted_last for st in sts]          # this round re-prefills the whole window
-        forced = []
-        orig_forced = bm.Story.forced
-
-        def capture(st):
-            f = orig_forced(st)
-            forced.append(f)
-            return f
-        bm.Story.forced = capture
-        try:
-            bm.mllm_part(sts, self.eng, self.rin, self.rout, self.vit, True)
-        finally:
-            bm.Story.forced = orig_forced
+        bm.mllm_part(sts, self.eng, self.rin, self.rout, self.vit, True)
+        forced = [st.last_forced for st in sts]                  # the round's forced ids, recorded by mllm_part
         # payload: forced / generated ids, the image features appended this round, the KV rows a later owner needs
         ids = torch.tensor(forced, dtype=torch.int32, device=self.device)                       # [S, 115]
         n_new = 2 if first else 1                                 # step 0 also appends the first image's ViT feature
@@ -272,21 +267,20 @@ class StoryRingBackend(SlotRingBackend):
                 # (from story step WINDOW on this is every round: 0 bytes of KV instead of 913 rows x 0.5 MiB per story)
                 lo = hi = 0
             self.eng.select(b)
-            tensors += [self.eng.k_cache[:, :, lo:hi].contiguous(), self.eng.v_cache[:, :, lo:hi].contiguous()]
+            tensors += [self.eng.k_cache[:, :, lo:hi], self.eng.v_cache[:, :, lo:hi]]      # views: packed without a staging copy
             meta += [lo, hi]
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
         return meta, tensors
 
     def alloc(self, meta):
         spg, T, n_new = meta[0], meta[1], meta[2]
         e = self.eng
-        out = [torch.empty(spg, T, dtype=torch.int32, device=self.device),
-               torch.empty(spg, n_new, 256, e.hidden, dtype=self.dtype, device=self.device)]
+        # DESCRIPTORS only (meta tensors: shape + dtype): the receive side allocates ONE flat buffer and views into it
+        out = [torch.empty(spg, T, dtype=torch.int32, device="meta"),
+               torch.empty(spg, n_new, 256, e.hidden, dtype=self.dtype, device="meta")]
         for b in range(spg):
             lo, hi = meta[4 + 2 * b], meta[5 + 2 * b]
             shp = (e.n_layers, e.n_heads, hi - lo, e.hd)
-            out += [torch.empty(shp, dtype=self.dtype, device=self.device), torch.empty(shp, dtype=self.dtype, device=self.device)]
+            out += [torch.empty(shp, dtype=self.dtype, device="meta"), torch.empty(shp, dtype=self.dtype, device="meta")]
         return out
 
     def apply(self, r, meta, tensors):
@@ -342,7 +336,19 @@ def bench_slot_partition(args, rank, world, device, dtype, bm):
     mine = run_slot_ring(be, args.steps, rank, world, meta_device=meta_dev)
     torch.cuda.synchronize()
     dist.barrier()
-    dt_s = max_over_ranks(time.perf_counter() - t0, "cpu" if gloo else device)
+    my_s = time.perf_counter() - t0
+    dt_s = max_over_ranks(my_s, "cpu" if gloo else device)
+    mine_t = torch.tensor([my_s, float(len(mine))], dtype=torch.float64, device="cpu" if gloo else device)
+    every = [torch.zeros_like(mine_t) for _ in range(world)]
+    dist.all_gather(every, mine_t)
+    per_rank = [{"rank": i, "seconds": round(float(v[0]), 4), "rounds_rendered": int(v[1]),
+                 "story_steps_rendered": int(v[1]) * args.stories_per_gpu} for i, v in enumerate(every)]
+    roof = cpu = None
+    if rank == 0:       # the same roofline section as the replica partition (rank 0's engines); CPU baseline at N = 1 only
+        roof = None if args.no_roofline else bm.measure_roofline(eng, adapter, args.stories_per_gpu, 1, device, dtype, args)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = bm.cpu_baseline(with_sdxl=not args.mllm_only, diffusion_steps=args.diffusion_steps)
+    dist.barrier()
     if hasattr(bm, "flush_c_stdio"):
         bm.flush_c_stdio()          # RCCL's version banner (C stdio) goes out before the JSON line, not behind it at exit
     if rank == 0:
@@ -357,9 +363,10 @@ def bench_slot_partition(args, rank, world, device, dtype, bm):
                                       % (spg, bm.STORY_LEN, world),
                           "partition": "slots", "stories_per_gpu": spg, "diffusion_steps": args.diffusion_steps,
                           "parallelism": "slot ring x%d (rotating owner, KV-cache broadcast over xGMI)" % world},
-               "rounds_rendered_by_rank0": mine, "backend": dist.get_backend(),
+               "rounds_rendered_by_rank0": mine, "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+               "per_rank": per_rank,
                "collectives_per_round": "1 header + 1 flat payload broadcast (ids, image feature, appended KV rows; no KV rows "
                                         "for a round whose context update evicted an image)",
-               "roofline": None, "cpu_baseline": None}
+               "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     dist.destroy_process_group()

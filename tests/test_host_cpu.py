@@ -276,6 +276,8 @@ def fake_mllm_part(sts, eng, rin, rout, vit, kv_reuse):
             assert float(eng.k_cache[0, 0, row, 0]) == row_val(st.seed, st.ids, row, []), (rank, b, st.step, row)
         st._S, st._keep = S, keep
     forced = [st.forced() for st in sts]
+    for st, f in zip(sts, forced):
+        st.last_forced = f
     for b, st in enumerate(sts):
         eng.select(b)
         for row in range(st._keep, st._S + 114):
