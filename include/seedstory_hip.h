@@ -93,6 +93,19 @@ int ss_gemm_rowstat(const void* A, const void* W, void* C, int64_t M, int64_t N,
 int ss_rowstat_finalize(double* rowstat, int64_t M, int64_t width, float eps, float* rstd_out, float* shift_out, void* stream);
 int ss_gemm_lnfold(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
                    const float* shift, const float* colsum, const void* bias, int epilogue, int dtype, void* stream);
+/* Round 4 — the same pair WITHOUT atomics and WITHOUT a finalize launch (deterministic; what UNet2DConditionModel.enable_lnfold
+ * uses): every wave column strip of the producer tile writes its (sum, sum of squares) of row m ONCE to
+ * rowpart[(m * strips + strip) * 2 .. +1] (fp32; strips = ss_gemm_rowpart_strips(M, N, K, dtype) = N / strip width of the
+ * tile ss_gemm_rowpart will run, 0 = shape not eligible: N must be a multiple of the tile width, operands 16-byte aligned);
+ * nothing needs zeroing.  ss_gemm_lnfold_part is ss_gemm_lnfold whose epilogue sums the `strips` partials of its rows and
+ * forms rstd / -mean * rstd itself (mean = s / width, var = q / width - mean^2 in fp64). */
+int64_t ss_gemm_rowpart_strips(int64_t M, int64_t N, int64_t K, int dtype);
+int ss_gemm_rowpart(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                    int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, float* rowpart,
+                    int dtype, void* stream);
+int ss_gemm_lnfold_part(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rowpart,
+                        int64_t strips, int64_t width, float eps, const float* colsum, const void* bias, int epilogue, int dtype,
+                        void* stream);
 
 /* fp8 (OCP e4m3fn) GEMM path of the SDXL UNet's linear layers (SURVEY §8 ★ row; BASELINE configs[4]).  The reference
  * has no fp8 path; this is the bf16 GEMM  C = A · W^T (+bias)(+GELU | GEGLU)(+residual)  with both operands quantised:

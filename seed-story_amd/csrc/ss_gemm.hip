@@ -564,10 +564,22 @@ static void conv_geometry(GemmArgs& g, int64_t B, int64_t H, int64_t Wd, int64_t
     g.conv_Ho = (int)Ho; g.conv_Wo = (int)Wo;
 }
 
+// tile of a statistics-producing GEMM (ss_gemm_rowstat / ss_gemm_rowpart): the shape's own tile when it has a statistics
+// instantiation, else the 160- / 128-wide staged tile; *bn = tile width, *tn = one wave's column strip
+template <typename T>
+static int rowstat_cfg(GemmArgs& g, int* bn, int* tn) {
+    int cfg = lookup_cfg<T>(g);
+    const bool has = cfg == 61 || cfg == 62 || cfg == 63 || cfg == 64 || cfg == 65 || cfg == 67 || cfg == 71 || cfg == 72;
+    if (!has) cfg = g.N % 160 == 0 ? (g.M >= 2048 ? 62 : 61) : 65;
+    *bn = (cfg == 63 || cfg == 72) ? 320 : cfg == 65 ? 128 : 160;
+    *tn = cfg == 65 ? 64 : 80;
+    return cfg;
+}
+
 template <typename T>
 int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                 int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, hipStream_t s,
-                double* rowstat_out = nullptr) {
+                double* rowstat_out = nullptr, float* rowpart = nullptr) {
     constexpr int V = Tr<T>::kVec;
     SS_REQUIRE(K % V == 0 && lda % V == 0 && ldw % V == 0, "gemm: K/lda/ldw must be multiples of %d (K=%lld)", V,
                (long long)K);
@@ -584,7 +596,7 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
     g.swz = tuning_get("gemm_xcd_swizzle", 8);
     if (tuning_get("gemm_epi_generic", 0)) g.epi |= SS_EPI_INTERNAL_GENERIC;
-    if (rowstat_out) {
+    if (rowstat_out || rowpart) {
         // statistics epilogue: only the staged software-pipelined tiles 61..72 have it (ids + 200); 256x256 tiles (60 / 69)
         // and non-staged choices fall to the 160- / 128-wide staged tile of the shape
         if constexpr (Tr<T>::kVec != 8) {
@@ -594,9 +606,15 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
             SS_REQUIRE(K % 64 == 0 && N % 8 == 0 && M > 128, "ss_gemm_rowstat: needs K %% 64 == 0, N %% 8 == 0, M > 128 (M=%lld N=%lld K=%lld)",
                        (long long)M, (long long)N, (long long)K);
             g.rowstat_out = rowstat_out;
-            int cfg = lookup_cfg<T>(g);
-            const bool has = cfg == 61 || cfg == 62 || cfg == 63 || cfg == 64 || cfg == 65 || cfg == 67 || cfg == 71 || cfg == 72;
-            if (!has) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : 65;
+            int bn = 0, tn = 0;
+            const int cfg = rowstat_cfg<T>(g, &bn, &tn);
+            if (rowpart) {      // partial sums per wave column strip: needs the staged epilogue on every wave
+                constexpr size_t A16 = 15;
+                SS_REQUIRE(N % bn == 0 && (((size_t)C | (size_t)residual | (size_t)bias) & A16) == 0 && ((ldc | ldr) & 7) == 0,
+                           "ss_gemm_rowpart: N %% %d != 0 or operands not 16-byte aligned (N=%lld)", bn, (long long)N);
+                g.rowpart = rowpart;
+                g.rowpart_ld = (int)(N / tn);
+            }
             const int rc = gemm_sp_dispatch<T>(cfg + 200, g, s);
             if (rc == 1) {
                 set_error("ss_gemm_rowstat: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 200, (long long)M, (long long)N, (long long)K);
@@ -647,7 +665,8 @@ int conv_tune_launch(int64_t B, int64_t H, int64_t Wd, int64_t Cin, int64_t Cout
 // in its folded-epilogue instantiation (id + 100: the staged family 60..72).
 template <typename T>
 int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,
-                       const float* shift, const float* colsum, const void* bias, int epi, hipStream_t s) {
+                       const float* shift, const float* colsum, const void* bias, int epi, hipStream_t s,
+                       const float* ln_part = nullptr, int64_t ln_nstrip = 0, int64_t ln_width = 0, float ln_eps = 0.f) {
     if constexpr (Tr<T>::kVec != 8) {
         set_error("ss_gemm_lnfold: 16-bit dtypes only");
         return SS_EINVAL;
@@ -655,7 +674,8 @@ int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_
         SS_REQUIRE(K % 64 == 0 && N % 16 == 0, "ss_gemm_lnfold: K %% 64 and N %% 16 must be 0 (K=%lld N=%lld)", (long long)K, (long long)N);
         SS_REQUIRE(!(epi & ~(SS_EPI_BIAS | SS_EPI_GELU | SS_EPI_GEGLU_PAIR)), "ss_gemm_lnfold: unsupported epilogue %d", epi);
         SS_REQUIRE(!(epi & SS_EPI_BIAS) || bias, "ss_gemm_lnfold: bias epilogue without bias");
-        SS_REQUIRE(rstd && shift && colsum && (((size_t)colsum) & 15) == 0, "ss_gemm_lnfold: row / column vectors missing or misaligned");
+        SS_REQUIRE(((rstd && shift) || (ln_part && ln_nstrip > 0 && ln_width > 0)) && colsum && (((size_t)colsum) & 15) == 0 &&
+                   (((size_t)ln_part) & 7) == 0, "ss_gemm_lnfold: row statistics / column vector missing or misaligned");
         if (M == 0 || N == 0) return SS_OK;
         GemmArgs g;
         g.A = A; g.W = Wg; g.C = C; g.bias = bias; g.residual = nullptr;
@@ -664,8 +684,15 @@ int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_
         g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
         g.swz = tuning_get("gemm_xcd_swizzle", 8);
         g.scale_a = rstd; g.shift_a = shift; g.scale_w = colsum;
+        g.ln_part = ln_part; g.ln_nstrip = (int)ln_nstrip; g.ln_inv_width = ln_width > 0 ? 1.0f / (float)ln_width : 0.f; g.ln_eps = ln_eps;
         int cfg = lookup_cfg<T>(g);
         if (cfg < 60 || cfg > 72) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : (M * N >= 128 * 128 * 256 ? 65 : 70);
+        // Round 4: the folded epilogue runs on the 8-wave tiles only.  On the 4-wave tiles (61 / 65 / 67 / 68 / 70: two
+        // workgroups per CU) it sporadically returns ONE wrong element per 16-row strip of the last fragment column of a wave
+        // (tools/dbg_lnfold_vec.py: 16-128 bad rows per 4 launches at [32768, 640, 640]; the plain epilogue on the same tiles and
+        // the folded one on the 8-wave tiles: none in the same runs) — cause not found, so those tiles are not offered.
+        if (cfg == 61 || cfg == 67) cfg = 62;
+        else if (cfg == 65 || cfg == 68 || cfg == 70) cfg = N % 160 == 0 ? 62 : 66;
         const int rc = gemm_sp_dispatch<T>(cfg + 100, g, s);
         if (rc == 1) {
             set_error("ss_gemm_lnfold: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 100, (long long)M, (long long)N, (long long)K);
@@ -894,6 +921,33 @@ int ss_rowstat_finalize(double* rowstat, int64_t M, int64_t width, float eps, fl
 int ss_rowstats(const void* x, int64_t ld, int64_t M, int64_t K, float eps, float* rstd_out, float* shift_out, int dtype, void* stream) {
     SS_REQUIRE(x && rstd_out && shift_out && M > 0 && K > 0 && ld >= K, "ss_rowstats: bad arguments");
     return SS_DISPATCH(dtype, ss::rowstats_launch, x, ld, M, K, eps, rstd_out, shift_out, (hipStream_t)stream);
+}
+
+int64_t ss_gemm_rowpart_strips(int64_t M, int64_t N, int64_t K, int dtype) {
+    if (dtype != SS_BF16 && dtype != SS_F16) return 0;
+    ss::GemmArgs g;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.conv_Cin = 0; g.epi = 0;
+    g.conv_H = g.conv_W = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
+    int bn = 0, tn = 0;
+    if (dtype == SS_BF16) ss::rowstat_cfg<ss::bf16_t>(g, &bn, &tn); else ss::rowstat_cfg<ss::f16_t>(g, &bn, &tn);
+    return (N % bn == 0) ? N / tn : 0;
+}
+
+int ss_gemm_rowpart(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                    int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epilogue, float* rowpart,
+                    int dtype, void* stream) {
+    SS_REQUIRE(rowpart && (((size_t)rowpart) & 7) == 0, "ss_gemm_rowpart: rowpart missing or not 8-byte aligned");
+    SS_REQUIRE(!(epilogue & SS_EPI_GEGLU_PAIR), "ss_gemm_rowpart: not defined for the GEGLU epilogue");
+    return SS_DISPATCH(dtype, ss::gemm_launch, A, W, C, M, N, K, lda, ldw, ldc, bias, residual, ldr, epilogue,
+                       (hipStream_t)stream, nullptr, rowpart);
+}
+
+int ss_gemm_lnfold_part(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rowpart,
+                        int64_t strips, int64_t width, float eps, const float* colsum, const void* bias, int epilogue, int dtype,
+                        void* stream) {
+    SS_REQUIRE(A && Wg && C && rowpart && strips > 0 && width > 0, "ss_gemm_lnfold_part: bad arguments");
+    return SS_DISPATCH(dtype, ss::gemm_lnfold_launch, A, Wg, C, M, N, K, ldc, nullptr, nullptr, colsum, bias, epilogue, (hipStream_t)stream,
+                       rowpart, strips, width, eps);
 }
 
 int ss_gemm_lnfold(const void* A, const void* Wg, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const float* rstd,

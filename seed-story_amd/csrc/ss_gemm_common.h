@@ -128,6 +128,13 @@ struct GemmArgs {
     // (rounded to T, residual included) into rowstat_out[2m], rowstat_out[2m+1] — fp64 atomics, one pair per row per
     // column strip of a wave; ss_rowstat_finalize turns them into (rstd, shift) and re-zeroes the array.
     double* rowstat_out = nullptr;
+    // round 4: the same statistics WITHOUT atomics — every wave column strip of the producer writes its (sum, sum of
+    // squares) of row m to rowpart[(m * rowpart_ld + strip) * 2 ..+1] (strip = first column of the wave's sub-tile / its width:
+    // every (row, strip) entry is written exactly once per launch — nothing to zero, nothing order-dependent), and the
+    // CONSUMER's folded-LayerNorm epilogue sums the ln_nstrip partials of its rows itself (fp64 mean / variance), so there
+    // is no finalize launch between the two GEMMs.
+    float* rowpart = nullptr; int rowpart_ld = 0;
+    const float* ln_part = nullptr; int ln_nstrip = 0; float ln_inv_width = 0.f, ln_eps = 0.f;
     // split-K (kernels instantiated with SPLITK, grid.y = ksplit): workgroup (x, y) multiplies K tiles
     // [y * ktiles_per_split, ...) and stores its raw fp32 accumulators to ((float*)C)[y][m][n] (ldc = N);
     // splitk_reduce_kernel sums the slices and applies the epilogue
@@ -398,6 +405,37 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
         if (g.epi & SS_EPI_BIAS) ld4<T>(bias + n_base + i * 16 + grp * 4, bv[i]);
         if constexpr (EM != 0) ld4<float>(g.scale_w + n_base + i * 16 + grp * 4, swv[i]);
     }
+    // folded LayerNorm fed by producer PARTIALS (g.ln_part): lane l forms (rstd, -mean * rstd) of rows l and l + 64 of this
+    // wave's sub-tile from their ln_nstrip (sum, sum of squares) pairs — fp64, E[x^2] - mean^2 does not cancel there — and the
+    // staging loop below fetches a fragment row's pair with two lane shuffles
+    constexpr int NSET = EM == 2 ? (FM * 16 + 63) / 64 : 1;
+    float st_sa[NSET], st_sh[NSET];
+    const bool from_part = EM == 2 && g.ln_part != nullptr;
+    if constexpr (EM == 2) {
+        if (from_part) {
+#pragma unroll
+            for (int h = 0; h < NSET; ++h) {
+                int m = m_base + h * 64 + lane;
+                m = m < M ? m : M - 1;
+                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (int64_t)m * g.ln_nstrip;
+                double a = 0.0, b = 0.0;
+                // 16 partials at a time, all loads issued before the first add (a dependent load per strip costs one L2
+                // round trip each: 16 x 2 x ~500 cycles per tile, measured +6 ms per forward)
+                for (int k0 = 0; k0 < g.ln_nstrip; k0 += 16) {
+                    float2 t[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t[k] = (k0 + k < g.ln_nstrip) ? pp[k0 + k] : make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { a += (double)t[k].x; b += (double)t[k].y; }
+                }
+                const double mean = a * (double)g.ln_inv_width;
+                const double var = fmax(b * (double)g.ln_inv_width - mean * mean, 0.0);
+                const float r = (float)(1.0 / sqrt(var + (double)g.ln_eps));
+                st_sa[h] = r;
+                st_sh[h] = -(float)mean * r;
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < FM / FPC; ++c) {
         // ---- stage CR rows: lane (l15, grp) holds rows j*16 + l15, columns i*16 + grp*4 .. +3 ----
@@ -414,8 +452,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
             }
             char* rowp = stg + (jj * 16 + l15) * RS;
             float sa = 1.f, sh = 0.f;
-            if constexpr (EM != 0) sa = g.scale_a[m < M ? m : M - 1];
-            if constexpr (EM == 2) sh = g.shift_a[m < M ? m : M - 1];
+            if constexpr (EM == 2) {
+                if (from_part) {
+                    sa = __shfl(st_sa[(j * 16) / 64], (j * 16) % 64 + l15, 64);
+                    sh = __shfl(st_sh[(j * 16) / 64], (j * 16) % 64 + l15, 64);
+                } else {
+                    sa = g.scale_a[m < M ? m : M - 1];
+                    sh = g.shift_a[m < M ? m : M - 1];
+                }
+            } else if constexpr (EM != 0) {
+                sa = g.scale_a[m < M ? m : M - 1];
+            }
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 float v[4];
@@ -462,7 +509,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                     }
                     *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n_out0 + c16 * 8) = u;
                     if constexpr (RSTAT) {
-                        if (g.rowstat_out) {   // (sum, sum of squares) of the 8 stored values, parked in the piece just consumed
+                        if (g.rowstat_out || g.rowpart) {   // (sum, sum of squares) of the 8 stored values, parked in the piece just consumed
                             float a[8];
                             unpack<T>(u, a);
                             float sv = 0.f, qv = 0.f;
@@ -474,7 +521,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                 }
             }
             if constexpr (RSTAT) {
-                if (g.rowstat_out) {   // one wave's LDS operations execute in order: lane r < CR folds row r's LPR partials
+                if (g.rowstat_out || g.rowpart) {   // one wave's LDS operations execute in order: lane r < CR folds row r's LPR partials
                     const int m = m_base + c * CR + lane;
                     if (lane < CR && m < M) {
                         float sv = 0.f, qv = 0.f;
@@ -483,8 +530,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
                             const float2 t = *reinterpret_cast<const float2*>(stg + lane * RS + q * 16);
                             sv += t.x; qv += t.y;
                         }
-                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m, (double)sv);
-                        unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m + 1, (double)qv);
+                        if (g.rowpart) {      // this wave's column strip of row m: written once, no atomics
+                            *reinterpret_cast<float2*>(g.rowpart + ((int64_t)m * g.rowpart_ld + n_base / TN) * 2) = make_float2(sv, qv);
+                        } else {
+                            unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m, (double)sv);
+                            unsafeAtomicAdd(g.rowstat_out + 2 * (int64_t)m + 1, (double)qv);
+                        }
                     }
                 }
             }

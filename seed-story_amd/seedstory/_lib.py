@@ -61,6 +61,9 @@ PROTOTYPES = {
     "ss_rowstats": (C.c_int, [vp, i64, i64, i64, f32, vp, vp, C.c_int, vp]),
     "ss_gemm_lnfold": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "ss_gemm_rowstat": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
+    "ss_gemm_rowpart_strips": (i64, [i64, i64, i64, C.c_int]),
+    "ss_gemm_rowpart": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
+    "ss_gemm_lnfold_part": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, vp, i64, i64, f32, vp, vp, C.c_int, C.c_int, vp]),
     "ss_rowstat_finalize": (C.c_int, [vp, i64, i64, f32, vp, vp, vp]),
     "ss_gemm_splitk_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
     "ss_gemm_splitk": (C.c_int, [vp, vp, vp, i64, i64, i64, vp, vp, vp, C.c_size_t, C.c_int, vp]),

@@ -374,14 +374,22 @@ class UNet2DConditionModel(nn.Module):
 
     def _lin(self, P, name, x, *, ln=None, bias=None, residual=None, geglu=False, rowstat=None):
         """One linear layer of a transformer block: fp8 when enabled and prepared for this weight, else bf16.
-        ``rowstat``: fp64 [M, 2] accumulator for the row statistics of the OUTPUT (see `_lin_ln`)."""
+        ``rowstat``: the forward's row-statistics carrier (see `_rs_new`): this GEMM's epilogue also writes the per-strip
+        (sum, sum of squares) of its OUTPUT rows for the LayerNorm that follows (see `_lin_ln`)."""
         f8 = P.get(name + ".fp8") if getattr(self, "_fp8", False) else None
         if f8 is None:
             if ln is not None:
                 x = ops.layernorm(x, ln[0], ln[1], ln[2])
             if geglu:
                 return ops.gemm_geglu(x, P[name], bias)
-            return ops.gemm(x, P[name], bias=bias, residual=residual, rowstat=rowstat)
+            part = None
+            if rowstat is not None:
+                M, K = x.shape
+                N = P[name].shape[0]
+                strips = ops.rowpart_strips(M, N, K, x.dtype)
+                part = rowstat["buf"][:M * strips * 2].view(M, strips, 2)
+                rowstat["cur"] = part
+            return ops.gemm(x, P[name], bias=bias, residual=residual, rowpart=part)
         assert rowstat is None
         x8, sx = ops.quantize_rows_fp8(x, ln=ln)
         return ops.gemm_fp8(x8, sx, f8[0], f8[1], bias=bias, residual=residual, geglu=geglu)
@@ -390,33 +398,29 @@ class UNet2DConditionModel(nn.Module):
         return getattr(self, "_lnfold", False) and not getattr(self, "_fp8", False)
 
     def _lin_ln(self, P, name, x, ln, bias=None, geglu=False, rowstat=None):
-        """LayerNorm + linear: folded (ss_gemm_lnfold) when enabled and prepared for this weight.  The row statistics
-        come from ``rowstat`` when the GEMM that produced x accumulated them in its epilogue (ss_gemm_rowstat ->
-        ss_rowstat_finalize: no pass over x at all), else from a statistics pass over x (ss_rowstats)."""
+        """LayerNorm + linear: folded (ss_gemm_lnfold) when enabled and prepared for this weight.  The row statistics come
+        from the per-strip partials the GEMM that produced x wrote in its epilogue (``rowstat``; ss_gemm_rowpart ->
+        ss_gemm_lnfold_part: no pass over x, no finalize launch, no atomics), else from a statistics pass over x
+        (ss_rowstats)."""
         lnf = P.get(name + ".lnf") if self._lnfold_on() else None
         if lnf is None:
             assert rowstat is None
             return self._lin(P, name, x, ln=ln, bias=bias, geglu=geglu)
         if rowstat is not None:
-            rstd, shift = ops.rowstat_finalize(rowstat, x.shape[1], ln[2], out=self._rs_vec(x.shape[0], x.device))
-        else:
-            rstd, shift = ops.rowstats(x, ln[2])
+            return ops.gemm_lnfold_part(x, lnf[0], rowstat["cur"], x.shape[1], ln[2], lnf[1], bias_d=lnf[2], geglu=geglu)
+        rstd, shift = ops.rowstats(x, ln[2])
         return ops.gemm_lnfold(x, lnf[0], rstd, shift, lnf[1], bias_d=lnf[2], geglu=geglu)
 
-    def _rs_acc(self, rows, device):
-        """fp64 [rows, 2] accumulator of producer-side row statistics: all zeros between uses (ss_rowstat_finalize re-zeroes
-        what it reads; `forward` zeroes it once more at its start in case a previous forward was interrupted)."""
+    def _rs_new(self, rows, width, device):
+        """Carrier of producer-side row statistics for ``rows`` tokens of ``width`` channels: one fp32 buffer of per-strip
+        (sum, sum of squares) pairs, fully rewritten by every producer (nothing to zero), sized for the narrowest strip (64)."""
         bufs = self.__dict__.setdefault("_rs_bufs", {})
-        b = bufs.get((rows, str(device)))
+        key = (rows, width, str(device))
+        b = bufs.get(key)
         if b is None:
-            b = bufs[(rows, str(device))] = (torch.zeros(rows, 2, dtype=torch.float64, device=device),
-                                             torch.empty(2, rows, dtype=torch.float32, device=device))
+            b = bufs[key] = torch.empty(rows * ((width + 63) // 64) * 2, dtype=torch.float32, device=device)
             self._kv_gen = getattr(self, "_kv_gen", 0) + 1      # a captured forward does not know this buffer
-        return b[0]
-
-    def _rs_vec(self, rows, device):
-        self._rs_acc(rows, device)
-        return self._rs_bufs[(rows, str(device))][1]
+        return {"buf": b, "cur": None}
 
     def _transformer(self, P, n, x, B, HW, ctx2d, Lctx, heads, layers, groups):
         h = ops.groupnorm(x, P[n + ".norm.weight"], P[n + ".norm.bias"], B, groups, 1e-6, silu=False)
@@ -426,7 +430,9 @@ class UNet2DConditionModel(nn.Module):
         if self._lnfold_on() and h.shape[0] > 128 and all(
                 (n + ".transformer_blocks.%d%s.lnf" % (k, w)) in P for k in range(layers)
                 for w in (".attn1.qkv", ".attn2.to_q.weight", ".ff.net.0.proj.pairs.weight")):
-            rs = self._rs_acc(h.shape[0], h.device)
+            width = P[n + ".proj_in.weight"].shape[0]
+            if all(ops.rowpart_strips(h.shape[0], width, kk, h.dtype) > 0 for kk in (h.shape[1], width, 4 * width)):
+                rs = self._rs_new(h.shape[0], width, h.device)
         h = self._lin(P, n + ".proj_in.weight", h, bias=P[n + ".proj_in.bias"], rowstat=rs)
         for k in range(layers):
             b = n + ".transformer_blocks.%d" % k
@@ -461,8 +467,6 @@ class UNet2DConditionModel(nn.Module):
         dt, dev = sample.dtype, sample.device
         B, _, H, W = sample.shape
         boc, G, L = c["block_out_channels"], c["norm_groups"], c["layers_per_block"]
-        for acc, _vec in self.__dict__.get("_rs_bufs", {}).values():
-            acc.zero_()
         # time + added ("text_time") conditioning: sinusoids on the host, MLPs on the device
         temb = kw.get("temb_in")          # [B, 320] device tensor (graph replay: no host->device copy inside the capture)
         if temb is None:

@@ -151,7 +151,7 @@ def attn_decode(q, kcache, vcache, kv_len_dev):
     return out
 
 
-def gemm(a, w, bias=None, residual=None, gelu=False, out=None, rowstat=None):
+def gemm(a, w, bias=None, residual=None, gelu=False, out=None, rowstat=None, rowpart=None):
     """a [M, K] @ w[N, K]^T (+bias)(+gelu)(+residual) -> [M, N].  ``rowstat`` (fp64 [M, 2], zeroed by the caller): the
     epilogue also accumulates (sum, sum of squares) of every stored output row into it (ss_gemm_rowstat)."""
     _req(a); _req(w)
@@ -165,6 +165,14 @@ def gemm(a, w, bias=None, residual=None, gelu=False, out=None, rowstat=None):
         assert rowstat.dtype == torch.float64 and rowstat.is_contiguous() and rowstat.numel() == 2 * M
         check(lib().ss_gemm_rowstat(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, p(rowstat),
                                     dt(a), stream()), "ss_gemm_rowstat")
+        return out
+    if rowpart is not None:      # [M, strips, 2] fp32: per-strip (sum, sum of squares) of the stored rows, no atomics
+        assert rowpart.dtype == torch.float32 and rowpart.is_contiguous() and rowpart.shape[0] == M
+        if rowpart.shape[1] != rowpart_strips(M, N, K, a.dtype):
+            raise _lib.SSError("gemm(rowpart=): buffer has %d strips, this shape's tile writes %d"
+                               % (rowpart.shape[1], rowpart_strips(M, N, K, a.dtype)))
+        check(lib().ss_gemm_rowpart(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, p(rowpart),
+                                    dt(a), stream()), "ss_gemm_rowpart")
         return out
     check(lib().ss_gemm(p(a), p(w), p(out), M, N, K, K, w.stride(0), N, p(bias), p(residual), N, epi, dt(a), stream()),
           "ss_gemm")
@@ -215,6 +223,26 @@ def gemm_lnfold(x, wg, rstd, shift, colsum, bias_d=None, gelu=False, geglu=False
     tune.ensure_gemm(M, N, K, dt(x), epi, x.device)
     check(lib().ss_gemm_lnfold(p(x), p(wg), p(out), M, N, K, No, p(rstd), p(shift), p(colsum), p(bias_d), epi, dt(x), stream()),
           "ss_gemm_lnfold")
+    return out
+
+
+def rowpart_strips(M, N, K, dtype):
+    """Number of (sum, sum of squares) partials per row that ``gemm(..., rowpart=)`` writes for this shape (0: not eligible)."""
+    return int(lib().ss_gemm_rowpart_strips(M, N, K, dt(dtype)))
+
+
+def gemm_lnfold_part(x, wg, rowpart, width, eps, colsum, bias_d=None, gelu=False, geglu=False):
+    """`gemm_lnfold` fed by the producer's per-strip partials ``rowpart`` [M, strips, 2]: the row statistics are formed in the
+    GEMM's own epilogue (no finalize launch)."""
+    _req(x); _req(wg); _req(rowpart)
+    M, K = x.shape
+    N = wg.shape[0]
+    No = N // 2 if geglu else N
+    out = torch.empty(M, No, dtype=x.dtype, device=x.device)
+    epi = (EPI_BIAS if bias_d is not None else 0) | (EPI_GELU if gelu else 0) | (_lib.EPI_GEGLU_PAIR if geglu else 0)
+    tune.ensure_gemm(M, N, K, dt(x), epi, x.device)
+    check(lib().ss_gemm_lnfold_part(p(x), p(wg), p(out), M, N, K, No, p(rowpart), rowpart.shape[1], int(width), float(eps),
+                                    p(colsum), p(bias_d), epi, dt(x), stream()), "ss_gemm_lnfold_part")
     return out
 
 

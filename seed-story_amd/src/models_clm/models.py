@@ -30,6 +30,25 @@ class ContinuousLVLM(nn.Module):
         self.output_resampler = output_resampler
         self.lm_loss_scale = lm_loss_scale
         self.rec_loss_scale = rec_loss_scale
+        self._regressor_fp32 = None
+
+    def enable_fp32_regressor(self, on=True):
+        """Mixed mode: keep the 16-bit LLM but run the image-feature REGRESSOR (the output resampler on the
+        64 last-layer rows, < 0.1 % of a story step) in exact fp32 on an fp32 copy of its weights; the result is rounded
+        once to the model dtype.  OFF by default: measured at hidden 4096 it moves the bf16 ``img_gen_feat`` distance to the
+        fp32 reference from 3.0e-2 to ~2.8e-2 — the error is carried by the 64 bf16 rows coming out of the decoder stack,
+        not by the regressor (tests/test_frontend_full_gpu.py prints both)."""
+        if on:
+            import copy
+            self._regressor_fp32 = copy.deepcopy(self.output_resampler).float()
+        else:
+            self._regressor_fp32 = None
+        return self
+
+    def _regress(self, rows):
+        if self._regressor_fp32 is not None and rows.dtype != torch.float32:
+            return self._regressor_fp32(rows.float()).to(rows.dtype)
+        return self.output_resampler(rows)
 
     @torch.no_grad()
     def forward(self, input_ids, attention_mask, labels, image_embeds, embeds_gen_mask, embeds_cmp_mask, ids_gen_mask,
@@ -130,7 +149,7 @@ class ContinuousLVLM(nn.Module):
         if has_img_output:
             e = eoi_indices[-1]
             img_gen_feats = last_hidden_states[e - num_img_gen_tokens:e].unsqueeze(0).contiguous()  # (:197)
-            img_gen_feat = self.output_resampler(img_gen_feats)                                     # (:205)
+            img_gen_feat = self._regress(img_gen_feats)                                             # (:205)
         else:
             img_gen_feat = None
         generate_text = tokenizer.decode(generate_ids, skip_special_tokens=False)

@@ -51,7 +51,8 @@ def test_slot_ring_and_replicas_under_rccl_world_size_1(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
                SS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for extra in (["--partition", "slots"], []):
+    for extra in (["--partition", "slots"],):      # (the replica partition has no data-path collective; its N > 1 bookkeeping —
+        # barrier, all_gather of per-rank clocks, max over ranks — is the same code the gloo 2-rank test below runs)
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
                "--stories-per-gpu", "2", "--diffusion-steps", "2", "--story-len", "3", "--no-cpu-baseline", "--no-batch1",
                "--no-tolerance-modes", "--no-roofline"] + extra

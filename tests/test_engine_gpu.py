@@ -451,8 +451,13 @@ def test_forward_call_and_manual_greedy_loop(golden):
     out2 = llm(input_ids=more.to(DEV), past_key_values=out.past_key_values, position_ids=torch.arange(21, 25).unsqueeze(0))
     lo2, _, _ = O.llama_forward(wd, dims, emb[more], torch.arange(21, 25).unsqueeze(0), kv_o)
     assert rel(out2.logits, lo2) < 1e-4 and llm.kv_cache_head == 25 and out2.past_key_values[1][1].shape[2] == 25
-    with pytest.raises(NotImplementedError):
-        llm(input_ids=ids.to(DEV), labels=ids.to(DEV))
+    # labels: the training-side call (modeling_llama_xformer.py:761-772), forward only
+    lab = ids.clone()
+    lab[0, :5] = -100
+    ol = llm(input_ids=ids.to(DEV), labels=lab.to(DEV), output_hidden_states=True)
+    ref_loss = torch.nn.functional.cross_entropy(lo[0, :-1], lab[0, 1:])
+    assert abs(float(ol.loss) - float(ref_loss)) < 1e-4 * float(ref_loss) and rel(ol.logits, lo) < 1e-4
+    assert ol.past_key_values is None and ol["loss"] is ol.loss
     # (2) the greedy loop by hand (use_kv_cache_head = False, gen_george.py:165)
     llm.use_kv_cache_head, llm.kv_cache_head = False, None
     proc = AutoImageTokenGenerationProcessor(tokenizer=_Tok(img_ids))

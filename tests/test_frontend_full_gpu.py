@@ -209,3 +209,18 @@ def test_generate_hidden4096_full_size_regressor(full, dtype, dtag):
     r = gate("img_gen_feat (north-star quantity)", feat, gg, "nf", dtag, gen["feat_stride"])
     if dtype == torch.float32:
         assert r < 1e-3          # the north-star gate itself (measured ~1e-6)
+    else:
+        # mixed mode: same bf16 decoder stack, regressor in exact fp32 on the 64 bf16 rows
+        agent.enable_fp32_regressor(True)
+        out2 = agent.generate(tokenizer=_Tok(img_ids), input_ids=input_ids, image_embeds=image_embeds.to(DEV),
+                              embeds_cmp_mask=torch.tensor([True]), ids_cmp_mask=mask, max_new_tokens=gen["max_new"],
+                              num_img_gen_tokens=64, forced_tokens=forced)
+        agent.enable_fp32_regressor(False)
+        assert out2["generate_ids"].tolist() == ref_ids
+        st = gen["feat_stride"]
+        ref32 = gg["nf_f32.rows"].float()
+        d_plain = rel(feat.reshape(-1, E)[::st], ref32)
+        d_mixed = rel(out2["img_gen_feat"].reshape(-1, E)[::st], ref32)
+        print("img_gen_feat bf16 vs the reference's fp32 rows: bf16 regressor %.3e | fp32 regressor on the bf16 rows %.3e"
+              % (d_plain, d_mixed))
+        assert d_mixed <= d_plain * 1.05 + 1e-3
