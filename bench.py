@@ -524,7 +524,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         # corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py -> profiles/round2_pmc_summary.json)
         traffic, under_render_us = None, None
         pmcj = {}
-        for name in ("round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
+        for name in ("round4_pmc_summary.json", "round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -672,11 +672,21 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         roof_mllm = roof
         from seedstory import tune as _tune
         ff1_cfg = _tune.lookup(Mg, Ng, Kg, 1)
-        ff1_traffic = pmcj.get("gemm_hbm_traffic", {}).get("ff1_%dx%dx%d" % (Mg, Ng, Kg), {}).get("hbm_bytes_per_launch") \
-            if pmcj.get("stories_per_gpu") == SPG else None
+        # the counters describe ONE tile table: a record collected on another table (or carrying no table hash: rounds 1-3) is
+        # refused rather than quoted (the round-3 line carried the ff1 over-fetch of a retired XCD group)
+        import hashlib
+        table_sha = hashlib.sha256(open(os.path.join(ROOT, "seed-story_amd", "seedstory", "tune_gfx950.json"), "rb").read()).hexdigest()[:16]
+        ghbm = pmcj.get("gemm_hbm_traffic", {})
+        ff1_rec = ghbm.get("ff1_%dx%dx%d_geglu" % (Mg, Ng, Kg)) or ghbm.get("ff1_%dx%dx%d" % (Mg, Ng, Kg)) or {}
+        traffic_ok = pmcj.get("stories_per_gpu") == SPG and pmcj.get("tile_table_sha16") == table_sha
+        ff1_traffic = ff1_rec.get("hbm_bytes_per_launch") if traffic_ok else None
+        traffic_note = ("HBM-side bytes per launch of the ff1 GEMM from profiles/round4_pmc_summary.json (collected on tile table %s)" % table_sha
+                        if ff1_traffic else "no PMC record for the shipped tile table (sha16 %s; record: %s) — traffic withheld"
+                        % (table_sha, pmcj.get("tile_table_sha16")))
         roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": ff1_traffic,
                 "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
+                "traffic_note": traffic_note, "tile_table_sha16": table_sha,
                 "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
                 "dominant_kernel": {"kernel": "ss::gemm_sp_kernel (tile table cfg %s) + GEGLU epilogue" % (ff1_cfg,),
                                     "shape_MNK": [Mg, Ng, Kg], "avg_launch_us": round(gemm_us, 1),

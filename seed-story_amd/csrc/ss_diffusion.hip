@@ -110,8 +110,14 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const double* _
         if (sidx < ns && g < G) {
             const int per = (nblk + ns - 1) / ns;
             const int k0 = sidx * per, k1 = min(nblk, k0 + per);
-            const double* pp = part + ((int64_t)b * nblk * G + g) * 2;
-            for (int k = k0; k < k1; ++k) { a1 += pp[(int64_t)k * G * 2]; a2 += pp[(int64_t)k * G * 2 + 1]; }
+            const double2* pp = reinterpret_cast<const double2*>(part) + (int64_t)b * nblk * G + g;
+            for (int kb = k0; kb < k1; kb += 8) {       // 8 independent loads in flight, then the adds in block order
+                double2 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = (kb + k < k1) ? pp[(int64_t)(kb + k) * G] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a1 += t[k].x; a2 += t[k].y; }
+            }
         }
         sl[threadIdx.x * 2] = a1;
         sl[threadIdx.x * 2 + 1] = a2;
