@@ -147,10 +147,16 @@ int ss_gemm_fp8(const void* A8, const float* scale_a, const void* W8, const floa
     g.conv_H = g.conv_W = g.conv_Cin = g.conv_stride = g.conv_up = g.conv_Ho = g.conv_Wo = 0;
     g.scale_a = scale_a; g.scale_w = scale_w;
     const int cfg = ss::pick_cfg_fp8(M, N, K);
-    const int mt = (cfg == 85 || cfg == 86) ? 64 : cfg == 82 ? 256 : 128;
+    const int mt = (cfg == 85 || cfg == 86) ? 64 : (cfg == 82 || cfg >= 90) ? 256 : 128;
     g.swz = ss::tuning_get("gemm_fp8_swz", (int)((M + mt - 1) / mt) >= 16 ? 8 : 0);
     if (ss::tuning_get("gemm_fp8_debug", 0)) fprintf(stderr, "ss_gemm_fp8 [%lld,%lld,%lld] epi %d cfg %d swz %d\n", (long long)M, (long long)N, (long long)K, epilogue, cfg, g.swz);
-    const int rc = ss::gemm_sp_dispatch_fp8(cfg, g, (hipStream_t)stream);
+    int rc = 1;
+    if (cfg >= 90) {        // 4-wave / AGPR-accumulator 256x256 tile (ss_gemm_w4.inc); ineligible shapes take the 8-wave 256x160 tile
+        rc = ss::gemm_w4_dispatch_fp8(cfg, g, (hipStream_t)stream);
+        if (rc == 1) rc = ss::gemm_sp_dispatch_fp8(82, g, (hipStream_t)stream);
+    } else {
+        rc = ss::gemm_sp_dispatch_fp8(cfg, g, (hipStream_t)stream);
+    }
     if (rc == 1) {
         ss::set_error("ss_gemm_fp8: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg, (long long)M, (long long)N, (long long)K);
         return SS_EINVAL;

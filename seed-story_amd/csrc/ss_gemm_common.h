@@ -551,5 +551,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
 template <typename T> int gemm_sp_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
 // fp8 (e4m3) operands, bf16 results: ss_gemm_sp_fp8.hip
 int gemm_sp_dispatch_fp8(int cfg, const GemmArgs& g, hipStream_t s);
+// fp8 on the 4-wave / AGPR-accumulator tiles (cfg 95, 96): ss_gemm_w4_fp8.hip
+int gemm_w4_dispatch_fp8(int cfg, const GemmArgs& g, hipStream_t s);
 
 }  // namespace ss

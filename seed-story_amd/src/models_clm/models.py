@@ -40,7 +40,13 @@ class ContinuousLVLM(nn.Module):
         not by the regressor (tests/test_frontend_full_gpu.py prints both)."""
         if on:
             import copy
-            self._regressor_fp32 = copy.deepcopy(self.output_resampler).float()
+            r = self.output_resampler
+            cache, r._cache = getattr(r, "_cache", None), {}      # the prepared-weights cache holds ctypes structs (not copyable)
+            try:
+                self._regressor_fp32 = copy.deepcopy(r).float()
+            finally:
+                if cache is not None:
+                    r._cache = cache
         else:
             self._regressor_fp32 = None
         return self

@@ -31,7 +31,7 @@ prof)
   python tools/summarize_round4.py stats;;
 pmc)
   rm -rf gpurun_out/r4/k_* gpurun_out/r4/a_* gpurun_out/r4/fetch gpurun_out/r4/write; mkdir -p gpurun_out/r4
-  CASES="8192,10240,1280,16:60/8 8192,3840,1280,0:60/8 8192,1280,1280,0,1:62/8 8192,1280,5120,0,1:62/4 c8,32,32,1280,1280,1,0,1:61/8 8192,8192,8192,0:60/8,91/8"
+  CASES="16384,10240,1280,16:69/0 8192,10240,1280,16:60/8 8192,3840,1280,0:60/8 8192,1280,1280,0,1:62/8 8192,1280,5120,0,1:62/4 c8,32,32,1280,1280,1,0,1:61/8 8192,8192,8192,0:60/8,91/8"
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))

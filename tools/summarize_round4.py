@@ -95,7 +95,7 @@ def derive(c, us):
 def cases_from_ubench():
     """gemm_ubench in PMC mode launches, per case with c cfgs: 1 reference + c checks + 3 per cfg (these are used)."""
     spec = open(os.path.join(R, "cases.txt")).read().split()
-    names = ["ff1_8192x10240x1280_geglu", "qkv_8192x3840x1280", "n1280res_8192x1280x1280", "ff2res_8192x1280x5120",
+    names = ["ff1_16384x10240x1280_geglu", "ff1_8192x10240x1280_geglu", "qkv_8192x3840x1280", "n1280res_8192x1280x1280", "ff2res_8192x1280x5120",
              "conv3x3_1280to1280_32x32_b8_rowvec", "gemm_8192cubed"]
     merged = collections.OrderedDict()
     for tag in sorted(glob.glob(os.path.join(R, "k_*"))):
@@ -183,7 +183,8 @@ else:
                       "write_bytes_per_launch": round(w * 1024), "dispatches": len(fe[k]["FETCH_SIZE"])}
     res["gemv_hbm_traffic"] = gem
     g = cases_from_ubench()
-    alg = {"ff1_8192x10240x1280_geglu": 2 * (8192 * 1280 + 10240 * 1280 + 8192 * 5120), "qkv_8192x3840x1280": 2 * (8192 * 1280 + 3840 * 1280 + 8192 * 3840),
+    alg = {"ff1_16384x10240x1280_geglu": 2 * (16384 * 1280 + 10240 * 1280 + 16384 * 5120),
+           "ff1_8192x10240x1280_geglu": 2 * (8192 * 1280 + 10240 * 1280 + 8192 * 5120), "qkv_8192x3840x1280": 2 * (8192 * 1280 + 3840 * 1280 + 8192 * 3840),
            "n1280res_8192x1280x1280": 2 * (8192 * 1280 + 1280 * 1280 + 2 * 8192 * 1280), "ff2res_8192x1280x5120": 2 * (8192 * 5120 + 1280 * 5120 + 2 * 8192 * 1280),
            "conv3x3_1280to1280_32x32_b8_rowvec": 2 * (8192 * 1280 + 1280 * 11520 + 8192 * 1280)}
     for k, v in g.items():
