@@ -383,14 +383,19 @@ def flush_c_stdio():
         pass
 
 
-def slot_groups(spg):
-    """Stories per GPU -> sizes of the lock-step decode groups (an engine sweeps the weights for <= 4 slots)."""
-    n = (spg + 3) // 4
+MAX_SLOTS = 8       # sequence slots of one engine = stories sharing one sweep of the weights per decode token
+
+
+def slot_groups(spg, max_slots=None):
+    """Stories per GPU -> sizes of the lock-step decode groups (an engine sweeps the weights once per token for <= 8 slots:
+    1 - 4 through the dot-product GEMV, 5 - 8 through the MFMA form)."""
+    m = max_slots or MAX_SLOTS
+    n = (spg + m - 1) // m
     return [spg // n + (1 if g < spg % n else 0) for g in range(n)]
 
 
 def build_engines(device, dtype, spg):
-    """One engine per group of <= 4 story slots, all over the same synthetic weight tensors."""
+    """One engine per group of <= MAX_SLOTS story slots, all over the same synthetic weight tensors."""
     engs, shared = [], None
     for n in slot_groups(spg):
         e, shared = build_engine(device, dtype, n, shared)
@@ -508,8 +513,13 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         # (qkv, o, gate|up per layer + lm_head: 97 launches/token) are ss::gemv_kernel<bf16,8,2,NB> and the down
         # projection a different symbol; with 3-4 slots every projection runs ss::gemv_ldsx_kernel<bf16,2,NB>
         # (129 launches/token), so the launch average is taken over all of them.
+        # With 5-8 slots the K=hidden projections run ss::gemv_mfma_kernel (v_mfma_f32_16x16x32, 8 waves = 8 K slices of a
+        # 16-row tile); the 11008-deep down projection is swept once per half of the slots by gemv_ldsx_kernel.
         if GRP <= 2:
             kern = "gemv_kernel<bf16_t,8,2,%d>" % GRP
+            n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
+        elif GRP > 4:
+            kern = "gemv_mfma_kernel<bf16_t>"
             n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
         else:
             kern = "gemv_ldsx_kernel<bf16_t,2,%d>" % GRP
@@ -798,6 +808,9 @@ def main():
                          "run as groups of <= 4 decode slots over shared weights and ONE render batch (UNet batch 2 x stories).  "
                          "Default: 8 for the replica partition (round 4, same box: 1.995 / 1.996 story-steps/s against 1.927 / 1.935 "
                          "with 4 — the batch-16 UNet forward costs 59.0 ms per 8 samples against 61.1), 4 for the slot ring")
+    ap.add_argument("--max-slots", type=int, default=0,
+                    help="sequence slots per decode engine (stories sharing one sweep of the weights per token): 1..8; "
+                         "default 8 (5 - 8 slots decode through the MFMA form of the GEMV)")
     ap.add_argument("--render-groups", type=int, default=0,
                     help="render the round's images as this many independent batches on separate HIP streams at once (de-tokenizer "
                          "replicas over equal weights); default 1.  Measured with 8 resident stories: 2 groups of 4 = 1.955 story-steps/s, one "
@@ -815,6 +828,9 @@ def main():
                          "regular GEMM tiles instead of the split-K weight-streaming path")
     ap.add_argument("--save-tune-table", default=None, help="write the GEMM tile table of this run to this JSON path")
     args = ap.parse_args()
+    if args.max_slots:
+        global MAX_SLOTS
+        MAX_SLOTS = max(1, min(8, args.max_slots))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

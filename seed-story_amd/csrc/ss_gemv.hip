@@ -17,6 +17,8 @@
 // :759 (lm_head); LlamaRMSNorm :107-115 for the prologue.
 #include "ss_common.h"
 
+#include <utility>
+
 namespace ss {
 
 struct GemvArgs {
@@ -330,6 +332,399 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(const GemvArgs a) {
     }
 }
 
+// ---- MFMA form: 5..16 sequences per sweep (16-bit types, K <= 4096) ----------------------------------------------------
+// Past 4 sequences the dot-product kernels above run out of VALU / LDS rate (8 sequences = 8 v_dot2 per 4 weight bytes
+// plus 8 LDS reads per pack), while one v_mfma_f32_16x16x32 consumes 1 KB of weights for up to SIXTEEN sequences in 8
+// passes: the matrix core turns the batched decode projection back into a pure weight stream.
+//   * operands: A = 16 weight rows x 32 k (lane l: row l & 15, k-chunk l >> 4: ONE 16-byte load per lane per step, 64
+//     contiguous bytes per row per instruction, the two halves of a 128-B line in consecutive instructions),
+//     B = the activations (lane l: sequence l & 15, same k-chunk), D[row][sequence] in 4 VGPRs;
+//   * a workgroup is 8 waves = 8 K slices of the same 16-row tile (K = 4096: 16 steps of 32 per wave); every wave keeps
+//     ITS slice of the activations in 64 VGPRs for the whole launch (loaded — and RMS-normalised, statistic summed
+//     across the 8 waves in a fixed order — once), so the stream loop issues nothing but weight loads;
+//   * persistent: one workgroup per CU walks row tiles blockIdx, +grid, ...; the weights of the NEXT half-tile are
+//     requested before the MFMAs of the current one (two register buffers of 8 steps), also across tile boundaries
+//     and across the barrier: 8 - 16 KB per wave stay in flight the whole launch;
+//   * per tile the 8 partial accumulators meet in LDS (double-buffered: one barrier per tile) and wave 0 applies the
+//     epilogue of gemv_store (bias, rounding, residual | SiLU(gate) * up with the [gate; up] rows as two MFMA chains).
+template <int N, typename F, int... I>
+__device__ __forceinline__ void gv_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void gv_static_for(F&& f) { gv_static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <typename T> __device__ __forceinline__ f32x4_t gv_mfma(const uint4& a, const uint4& b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t gv_mfma<bf16_t>(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t gv_mfma<f16_t>(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kGvWaves = 8, kGvSteps = 16, kGvChunk = 8;
+
+// the 8 waves' partial accumulators of one row tile -> LDS -> (barrier) -> wave 0 folds them in wave order and applies the
+// epilogue of gemv_store.  `part` = [8 waves][M][256] floats of this tile's parity.
+// The epilogue's residual / bias values of wave 0 are requested at the TOP of the tile (gv_epi_prefetch), ahead of the weight
+// loads: a load issued in the epilogue itself would have to be waited for with every younger weight prefetch in front of
+// it (vmcnt is in-order), which stalls wave 0 — and through the next barrier the whole workgroup — once per tile.
+struct GvEpi { uint2 res, bias; bool vec; };
+template <typename T>
+__device__ __forceinline__ GvEpi gv_epi_prefetch(const GemvArgs& a, int tile, int lane, bool vec_ok) {
+    GvEpi e;
+    e.vec = vec_ok;
+    e.res = make_uint2(0, 0);
+    e.bias = make_uint2(0, 0);
+    if (vec_ok) {       // kernel-uniform: N, y_ld, res_ld multiples of 4 -> 8-byte accesses of 4 consecutive rows
+        const int i = lane & 15, q = lane >> 4;
+        int row0 = tile * 16 + q * 4;
+        if (row0 > a.N - 4) row0 = a.N - 4;
+        const int seq = i < a.nb ? i : 0;
+        // (absent operands read the output row instead: in range, never used)
+        const T* rp = (a.epi & SS_EPI_RESIDUAL) ? (const T*)a.residual + (int64_t)seq * a.res_ld : (const T*)a.y + (int64_t)seq * a.y_ld;
+        const T* bp = (a.epi & SS_EPI_BIAS) ? (const T*)a.bias : (const T*)a.y + (int64_t)seq * a.y_ld;
+        e.res = *reinterpret_cast<const uint2*>(rp + row0);
+        e.bias = *reinterpret_cast<const uint2*>(bp + row0);
+    }
+    return e;
+}
+template <typename T> __device__ __forceinline__ float gv_elem(const uint2& v, int r) {
+    const uint32_t w = r < 2 ? v.x : v.y;
+    T t;
+    t.v = (uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu));
+    return Tr<T>::ld(&t);
+}
+
+template <typename T, bool SILU>
+__device__ __forceinline__ void gv_fold_store(const GemvArgs& a, float* part, const f32x4_t (&acc)[SILU ? 2 : 1], int tile,
+                                              int wave, int lane, const GvEpi& epi) {
+    constexpr int M = SILU ? 2 : 1;
+    const int i = lane & 15, q = lane >> 4;
+    const int N = a.N;
+#pragma unroll
+    for (int m = 0; m < M; ++m) *reinterpret_cast<f32x4_t*>(part + (wave * M + m) * 256 + lane * 4) = acc[m];
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4_t v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        v[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kGvWaves; ++w) v[m] += *reinterpret_cast<const f32x4_t*>(part + (w * M + m) * 256 + lane * 4);
+    }
+    const int row0 = tile * 16 + q * 4;                       // D[row 4q + r][sequence i]
+    if (i >= a.nb || row0 >= N) return;
+    T* y = (T*)a.y + (int64_t)i * a.y_ld;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + r < N ? row0 + r : N - 1;
+        if constexpr (SILU) {
+            const float gt = Tr<T>::rnd(v[0][r]), up = Tr<T>::rnd(v[M - 1][r]);
+            o[r] = Tr<T>::rnd(silu_g(gt)) * up;
+        } else {
+            float t = v[0][r];
+            if (epi.vec) {
+                if (a.epi & SS_EPI_BIAS) t += gv_elem<T>(epi.bias, r);
+                t = Tr<T>::rnd(t);
+                if (a.epi & SS_EPI_RESIDUAL) t += gv_elem<T>(epi.res, r);
+            } else {
+                if (a.epi & SS_EPI_BIAS) t += Tr<T>::ld((const T*)a.bias + row);
+                t = Tr<T>::rnd(t);
+                if (a.epi & SS_EPI_RESIDUAL) t += Tr<T>::ld((const T*)a.residual + (int64_t)i * a.res_ld + row);
+            }
+            o[r] = t;
+        }
+    }
+    if (row0 + 3 < N && ((a.y_ld | row0) & 3) == 0) {
+        T tmp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tr<T>::st(tmp + r, o[r]);
+        *reinterpret_cast<uint2*>(y + row0) = *reinterpret_cast<const uint2*>(tmp);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < N) Tr<T>::st(y + row0 + r, o[r]);
+    }
+}
+
+// any K <= 4096 (multiple of 8), any N: predicated loads — correct for every shape, with the prefetch serialised by the
+// predicates' branches (the tiny test models and odd widths; the LLaMA-7B depths take gemv_mfma_exact_kernel below)
+template <typename T, bool SILU>
+__global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvArgs a, const int spw, const int ntiles) {
+    constexpr int NS = kGvSteps, CH = kGvChunk, M = SILU ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float part[2][kGvWaves][M][256];
+    __shared__ float red[kGvWaves][16];
+    if (gemv_all_done(a)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int K = a.K, N = a.N, nb = a.nb;
+    const T* __restrict__ W = (const T*)a.W;
+    const int k0 = wave * spw * 32 + q * 8;                         // this lane's k at the wave's step 0
+    int nvalid = k0 < K ? (K - k0 + 31) / 32 : 0;                   // steps of this lane that lie inside K
+    if (nvalid > spw) nvalid = spw;
+
+    // ---- the wave's slice of the activations, in B-operand order (+ fused RMSNorm) -----------------------------------
+    // (lanes of sequences >= nb read sequence 0: their columns of D are never stored)
+    uint4 xf[NS];
+    {
+        const T* xr = (const T*)a.x + (int64_t)(i < nb ? i : 0) * a.x_ld + k0;
+        gv_static_for<NS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            xf[s] = s < nvalid ? ld16(xr + s * 32) : make_uint4(0, 0, 0, 0);
+        });
+        if (a.norm_w) {
+            float ssq = 0.f;
+            gv_static_for<NS>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                float f[8];
+                unpack<T>(xf[s], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ssq = fmaf(f[j], f[j], ssq);
+            });
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (lane < 16) red[wave][lane] = ssq;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kGvWaves; ++w) tot += red[w][i];
+            const float rstd = 1.0f / sqrtf(tot / (float)K + a.eps);
+            const T* gw = (const T*)a.norm_w + k0;
+            gv_static_for<NS>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                if (s < nvalid) {
+                    float f[8], g[8];
+                    unpack<T>(xf[s], f);
+                    unpack<T>(ld16(gw + s * 32), g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = g[j] * Tr<T>::rnd(f[j] * rstd);
+                    xf[s] = pack<T>(f);
+                }
+            });
+        }
+    }
+    uint4 wa[M][NS];
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        int row = tile * 16 + i;
+        if (row >= N) row = N - 1;
+        f32x4_t acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const T* p = W + ((int64_t)row + (int64_t)m * N) * K + k0;
+            gv_static_for<NS>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                wa[m][s] = s < nvalid ? ld_nt16(p + s * 32) : make_uint4(0, 0, 0, 0);
+            });
+        }
+        gv_static_for<NS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[m] = gv_mfma<T>(wa[m][s], xf[s], acc[m]);
+        });
+        GvEpi epi;
+        epi.vec = false;
+        gv_fold_store<T, SILU>(a, &part[it & 1][0][0][0], acc, tile, wave, lane, epi);
+    }
+}
+
+// ---- the predicate-free stream loop for the two LLaMA-7B depths ---------------------------------------------------------------
+// K == 8 waves x SPW steps x 32 exactly (SPW = 16: K = 4096, hidden; SPW = 43: K = 11008, the MLP width): every load of
+// every lane is in range, so the stream loop carries no predicate and no branch (a predicated load is a branch to hipcc, and
+// every branch join waits for vmcnt(0): the prefetch would be serialised).  The K slice of a wave is walked in chunks of 8
+// steps through two register buffers; the loads of chunk c + 1 (or of the next tile's chunk 0) are issued before the MFMAs
+// of chunk c, across the barrier too.
+// SPW = 43 (PACK): 43 activation fragments per lane would take 172 VGPRs; only sequences 0..7 exist (nb <= 8), so lanes
+// 8..15 of every 16-lane row carry steps 22..43 of sequences 0..7 and a row_shl:8 DPP move hands them to lanes 0..7 when
+// their step comes up: 88 VGPRs.  (Columns 8..15 of D then hold garbage that is never stored.)  No RMSNorm in this form.
+__device__ __forceinline__ void gv_fence(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+template <bool SHR>
+__device__ __forceinline__ uint4 gv_row_shift8(const uint4& v) {
+    constexpr int ctrl = SHR ? 0x118 : 0x108;      // row_shr:8 | row_shl:8
+    uint4 r;
+    r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, ctrl, 0xf, 0xf, true);
+    r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, ctrl, 0xf, 0xf, true);
+    r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, ctrl, 0xf, 0xf, true);
+    r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, ctrl, 0xf, 0xf, true);
+    return r;
+}
+
+template <typename T, bool SILU, int SPW, bool NT, bool SHR = false>
+__global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, const int ntiles) {
+    constexpr int CH = kGvChunk, M = SILU ? 2 : 1;
+    constexpr int NCH = (SPW + CH - 1) / CH;
+    constexpr bool PACK = SPW > kGvSteps;
+    constexpr int HALF = PACK ? (SPW + 1) / 2 : SPW;        // fragments a lane holds
+    static_assert(NCH % 2 == 0, "an even number of chunks keeps the buffer parity across tiles");
+    __shared__ __attribute__((aligned(16))) float part[2][kGvWaves][M][256];
+    __shared__ float red[kGvWaves][16];
+    if (gemv_all_done(a)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int K = a.K, N = a.N, nb = a.nb;
+    const T* __restrict__ W = (const T*)a.W;
+    const int k0 = wave * SPW * 32 + q * 8;                         // this lane's k at the wave's step 0
+    int tile = blockIdx.x, it = 0;
+    if (tile >= ntiles) return;
+
+    uint4 wa[2][M][CH];
+    auto load_chunk = [&](auto c_, int tl) {                        // chunk c of row tile tl -> buffer c & 1
+        constexpr int c = decltype(c_)::value;
+        int row = tl * 16 + i;
+        if (row >= N) row = N - 1;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const T* p = W + ((int64_t)row + (int64_t)m * N) * K + k0 + c * CH * 32;
+            gv_static_for<CH>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                if constexpr (c * CH + e < SPW) wa[c & 1][m][e] = NT ? ld_nt16(p + e * 32) : ld16(p + e * 32);
+            });
+        }
+    };
+
+    // ---- the wave's slice of the activations, in B-operand order (+ fused RMSNorm) -----------------------------------
+    uint4 xf[HALF];
+    if constexpr (!PACK) {
+        // (lanes of sequences >= nb read sequence 0: their columns of D are never stored)
+        const T* xr = (const T*)a.x + (int64_t)(i < nb ? i : 0) * a.x_ld + k0;
+        gv_static_for<HALF>([&](auto s_) { constexpr int s = decltype(s_)::value; xf[s] = ld16(xr + s * 32); });
+        load_chunk(std::integral_constant<int, 0>{}, tile);         // the first weights travel while the statistic is formed
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.norm_w) {
+            float ssq = 0.f;
+            gv_static_for<HALF>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                float f[8];
+                unpack<T>(xf[s], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ssq = fmaf(f[j], f[j], ssq);
+            });
+            // (the fragments are unpacked AGAIN below: without this fence hipcc keeps the 128 unpacked floats alive across
+            // the barrier and spills)
+            gv_static_for<HALF>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                gv_fence(xf[s]);
+            });
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (lane < 16) red[wave][lane] = ssq;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kGvWaves; ++w) tot += red[w][i];
+            const float rstd = 1.0f / sqrtf(tot / (float)K + a.eps);
+            const T* gw = (const T*)a.norm_w + k0;
+            // the gain in two batches of 8 fragments (32 VGPRs in flight, not 64: with the activations and the first weights
+            // resident the single batch spills)
+            gv_static_for<2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                uint4 gf[HALF / 2];
+                gv_static_for<HALF / 2>([&](auto s_) { constexpr int s = decltype(s_)::value; gf[s] = ld16(gw + (h * (HALF / 2) + s) * 32); });
+                gv_static_for<HALF / 2>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value, t = h * (HALF / 2) + s;
+                    float f[8], g[8];
+                    unpack<T>(xf[t], f);
+                    unpack<T>(gf[s], g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = g[j] * Tr<T>::rnd(f[j] * rstd);
+                    xf[t] = pack<T>(f);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    } else {
+        const int seq = i & 7, upper = i >> 3;
+        const T* xr = (const T*)a.x + (int64_t)(seq < nb ? seq : 0) * a.x_ld + k0 + upper * HALF * 32;
+        gv_static_for<HALF>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            if constexpr (s + HALF < SPW) xf[s] = ld16(xr + s * 32);
+            else {                                                  // step s + HALF does not exist: the upper lanes hold zeros
+                const uint4 v = ld16(xr + (upper ? s - 1 : s) * 32);
+                xf[s] = upper ? make_uint4(0, 0, 0, 0) : v;
+            }
+        });
+        load_chunk(std::integral_constant<int, 0>{}, tile);
+    }
+    const bool vec_ok = ((a.y_ld | a.res_ld | N) & 3) == 0 && N >= 4 && (a.epi & (SS_EPI_RESIDUAL | SS_EPI_BIAS));
+
+    // one row tile: per chunk — next chunk requested (the next TILE's first chunk behind the last one), this chunk consumed;
+    // then partial sums to LDS, barrier, wave 0 folds the 8 slices and stores
+    auto tile_body = [&](int tl, int itn, auto has_next_) {
+        constexpr bool has_next = decltype(has_next_)::value;
+        f32x4_t acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        GvEpi epi;
+        epi.vec = false;
+        if constexpr (!SILU) epi = gv_epi_prefetch<T>(a, tl, lane, vec_ok);
+        gv_static_for<NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            if constexpr (c + 1 < NCH) load_chunk(std::integral_constant<int, c + 1>{}, tl);
+            else if constexpr (has_next) load_chunk(std::integral_constant<int, 0>{}, tl + (int)gridDim.x);
+            __builtin_amdgcn_sched_barrier(0);      // the scheduler otherwise sinks these loads below the MFMAs that free
+            gv_static_for<CH>([&](auto e_) {        // their registers: one buffer in flight instead of two
+                constexpr int e = decltype(e_)::value, s = c * CH + e;
+                if constexpr (s < SPW) {
+                    uint4 b;
+                    if constexpr (!PACK) b = xf[s];
+                    else if constexpr (s < HALF) b = xf[s];
+                    else b = gv_row_shift8<SHR>(xf[s - HALF]);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) acc[m] = gv_mfma<T>(wa[c & 1][m][e], b, acc[m]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        gv_fold_store<T, SILU>(a, &part[itn & 1][0][0][0], acc, tl, wave, lane, epi);
+    };
+    for (; tile + (int)gridDim.x < ntiles; tile += gridDim.x, ++it) tile_body(tile, it, std::true_type{});
+    tile_body(tile, it, std::false_type{});
+}
+
+template <typename T>
+static bool gemv_mfma_eligible(const GemvArgs& a) {
+    if (a.K <= kGvWaves * kGvSteps * 32) return true;
+    // the packed 43-step form: the LLaMA-7B MLP width only, <= 8 sequences, no RMSNorm prologue
+    return a.K == kGvWaves * 43 * 32 && a.nb <= 8 && !a.norm_w && !tuning_get("gemv_mfma_generic", 0) &&
+           tuning_get("gemv_mfma_long", 1);
+}
+
+template <typename T>
+static int gemv_launch_mfma(const GemvArgs& a, hipStream_t s) {
+    const bool silu = (a.epi & SS_EPI_SILU_MUL) != 0;
+    const int ksteps = cdiv(a.K, 32);
+    const int spw = cdiv(ksteps, kGvWaves);
+    const int ntiles = cdiv(a.N, 16);
+    // whole rounds: ceil(tiles / 256) tiles per workgroup on as few workgroups as that takes (688 tiles -> 230 x 3, not 256
+    // workgroups of which 80 run a third round alone)
+    const int cus = tuning_get("gemv_mfma_blocks", 256);
+    const int rounds = cdiv(ntiles, cus);
+    const int blocks = cdiv(ntiles, rounds);
+    const bool generic = tuning_get("gemv_mfma_generic", 0) != 0;
+    const dim3 g((unsigned)blocks), b(512);
+#define SS_GV_EXACT(SPW)                                                                                                  \
+    do {                                                                                                                  \
+        if (silu) { if (a.use_nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, true, SPW, true>), g, b, 0, s, a, ntiles); \
+                    else hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, true, SPW, false>), g, b, 0, s, a, ntiles); }       \
+        else { if (a.use_nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, SPW, true>), g, b, 0, s, a, ntiles);     \
+               else hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, SPW, false>), g, b, 0, s, a, ntiles); }           \
+    } while (0)
+    if (!generic && a.K == kGvWaves * kGvSteps * 32) SS_GV_EXACT(16);
+    else if (!generic && a.K == kGvWaves * 43 * 32) {
+        if (tuning_get("gemv_mfma_dpp_shr", 0) && !silu) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, 43, true, true>), g, b, 0, s, a, ntiles);
+        else SS_GV_EXACT(43);
+    }
+    else if (silu) hipLaunchKernelGGL((gemv_mfma_kernel<T, true>), g, b, 0, s, a, spw, ntiles);
+    else hipLaunchKernelGGL((gemv_mfma_kernel<T, false>), g, b, 0, s, a, spw, ntiles);
+#undef SS_GV_EXACT
+    SS_LAUNCH_CHECK("gemv_mfma");
+    return SS_OK;
+}
+
 template <typename T, int NIT, int NB>
 static int gemv_launch_reg(const GemvArgs& a, int blocks, hipStream_t s) {
     // ROWS=2 keeps 16 x 16 B per lane in flight at NIT=8 (and SiLU pairs need exactly 2 rows)
@@ -391,8 +786,24 @@ int gemv_launch(const GemvArgs& a0, hipStream_t s) {
     SS_REQUIRE(!(epi & SS_EPI_SILU_MUL) || !(epi & (SS_EPI_BIAS | SS_EPI_RESIDUAL | SS_EPI_GELU)),
                "gemv: SILU_MUL cannot be combined with other epilogues");
     SS_REQUIRE(!(epi & SS_EPI_GELU), "gemv: GELU epilogue not supported");
-    SS_REQUIRE(a.nb >= 1 && a.nb <= 4, "gemv: batch %d unsupported (1..4)", a.nb);
+    SS_REQUIRE(a.nb >= 1 && a.nb <= 16, "gemv: batch %d unsupported (1..16)", a.nb);
     a.use_nt = tuning_get("gemv_nt", 1);
+    // 5+ sequences (or fewer, by knob): the MFMA form when the shape allows it (16-bit, 8 waves x 16 steps of 32 cover K)
+    if constexpr (V == 8) {
+        if (a.nb >= tuning_get("gemv_mfma_min_nb", 5) && gemv_mfma_eligible<T>(a)) return gemv_launch_mfma<T>(a, s);
+    }
+    if (a.nb > 4) {      // no MFMA form for this shape / type: two sweeps of half the sequences each
+        const int h1 = a.nb / 2;
+        GemvArgs lo = a, hi = a;
+        lo.nb = h1;
+        hi.nb = a.nb - h1;
+        hi.x = (const T*)a.x + (int64_t)h1 * a.x_ld;
+        hi.y = (T*)a.y + (int64_t)h1 * a.y_ld;
+        if (a.residual) hi.residual = (const T*)a.residual + (int64_t)h1 * a.res_ld;
+        if (a.done_flag) hi.done_flag = a.done_flag + (int64_t)h1 * a.done_stride;
+        const int rc = gemv_launch<T>(lo, s);
+        return rc ? rc : gemv_launch<T>(hi, s);
+    }
     const int nit = cdiv(K, 64 * V);
     const int64_t groups = (epi & SS_EPI_SILU_MUL) ? N : (N + 1) / 2;
     // waves: enough to fill the chip, but several row-groups per wave so the x prologue amortises

@@ -404,7 +404,7 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
     SS_REQUIRE(cfg && w && workspace && out, "llama_create: null argument");
     SS_REQUIRE(cfg->hidden % cfg->n_heads == 0, "llama_create: hidden %% n_heads != 0");
     SS_REQUIRE(cfg->n_img_ids <= 1024 && cfg->max_new > 0 && cfg->cache_cap > 0, "llama_create: bad config");
-    SS_REQUIRE(cfg->n_seq >= 0 && cfg->n_seq <= 4, "llama_create: n_seq=%d unsupported (1..4)", cfg->n_seq);
+    SS_REQUIRE(cfg->n_seq >= 0 && cfg->n_seq <= 8, "llama_create: n_seq=%d unsupported (1..8)", cfg->n_seq);
     // the decode loop's per-slot stop word packs the EOS id in 16 bits (and the optional second stop id + 1 above it)
     SS_REQUIRE(cfg->vocab > 0 && cfg->vocab <= 0xFFFF && cfg->eos_id < 0xFFFF,
                "llama_create: vocab %d / eos_id %d do not fit the 16-bit stop word (vocab <= 65535)", (int)cfg->vocab,

@@ -79,7 +79,7 @@ def test_llama_graph_equals_eager(golden):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize("n_seq", [2, 3, 4])
+@pytest.mark.parametrize("n_seq", [2, 3, 4, 6, 8])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_llama_slot_batched_decode_equals_single(golden, n_seq, dtype):
     """n_seq story slots decoded in lock-step (one sweep of the weights per token) must reproduce,

@@ -132,43 +132,75 @@ def test_gemv_silu_mul(ops, I, K, dtype):
     assert rel(y, ref) < (1e-5 if dtype == torch.float32 else 6e-3)
 
 
-@pytest.mark.parametrize("nb", [2, 3, 4])
+@pytest.mark.parametrize("nb", [2, 3, 4, 5, 8, 16])
 @pytest.mark.parametrize("N,K", [(512, 256), (4096, 4096), (4096, 11008), (1000, 1664)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemv_batched_rows_match_single(ops, nb, N, K, dtype):
     """Lock-step decode of nb story slots: row b of the batched sweep == the batch-1 kernel on row b
-    (same per-lane summation order in the register path; LDS-staged path within rounding)."""
+    (same per-lane summation order in the register path; LDS-staged path within rounding).  nb >= 5 in a 16-bit type with
+    K <= 4096 is the MFMA form (K = 4096: the predicate-free stream loop; K = 256 / 1664 and N = 1000: predicated loads,
+    ragged last row tile); fp32 and K = 11008 sweep the weights once per half of the sequences."""
     w = dev(synth.normal_like(70, (N, K), 0.05, dtype=dtype))
     x = dev(synth.normal_like(71, (nb, K), 1.0, dtype=dtype))
     res = dev(synth.normal_like(72, (nb, N), 1.0, dtype=dtype))
     nw = dev(synth.normal_like(73, (K,), 0.1, 1.0, dtype=dtype))
     tol = 1e-5 if dtype == torch.float32 else 4e-3
-    for kw in ({}, {"residual": True}, {"norm": True}):
+    bias = dev(synth.normal_like(76, (N,), 0.5, dtype=dtype))
+    for kw in ({}, {"residual": True}, {"norm": True}, {"norm": True, "bias": True, "residual": True}):
         r = res if kw.get("residual") else None
         n = nw if kw.get("norm") else None
-        yb = ops.gemv_batched(w, x, norm_w=n, eps=1e-5, residual=r)
-        for b in range(nb):
-            y1 = ops.gemv(w, x[b].contiguous(), norm_w=n, eps=1e-5, residual=None if r is None else r[b].contiguous())
+        bs = bias if kw.get("bias") else None
+        yb = ops.gemv_batched(w, x, norm_w=n, eps=1e-5, bias=bs, residual=r)
+        for b in range(nb if nb <= 4 else 2):
+            y1 = ops.gemv(w, x[b].contiguous(), norm_w=n, eps=1e-5, bias=bs, residual=None if r is None else r[b].contiguous())
             assert rel(yb[b], y1) < tol, (kw, b)
         xr = x.float().cpu()
         if n is not None:
             xr = torch.stack([O.rmsnorm(x[b].cpu(), nw.cpu(), 1e-5) for b in range(nb)]).float()
-        ref = (xr @ w.float().cpu().t()).to(dtype)
+        ref = xr @ w.float().cpu().t()
+        if bs is not None:
+            ref = ref + bias.float().cpu()
+        ref = ref.to(dtype)
         if r is not None:
             ref = (ref + res.cpu()).to(dtype)
         assert rel(yb, ref) < tol, kw
+        for b in range(nb):
+            assert rel(yb[b], ref[b]) < tol, (kw, b)
 
 
-@pytest.mark.parametrize("nb", [2, 4])
-def test_gemv_batched_silu(ops, nb):
-    I, K = 11008, 4096
-    dtype = torch.bfloat16
-    w = dev(synth.normal_like(74, (2 * I, K), 0.05, dtype=dtype))
+@pytest.mark.parametrize("nb", [2, 4, 6, 8])
+@pytest.mark.parametrize("I,K,dtype", [(11008, 4096, torch.bfloat16), (100, 512, torch.bfloat16), (11008, 4096, torch.float16)])
+def test_gemv_batched_silu(ops, nb, I, K, dtype):
+    w = dev(synth.normal_like(74, (2 * I, K), 0.02 if dtype == torch.float16 else 0.05, dtype=dtype))
     x = dev(synth.normal_like(75, (nb, K), 1.0, dtype=dtype))
     yb = ops.gemv_batched(w, x, silu_mul=True)
+    gu = (x.float().cpu() @ w.float().cpu().t()).to(dtype)
+    ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
     for b in range(nb):
         y1 = ops.gemv(w, x[b].contiguous(), silu_mul=True)
-        assert rel(yb[b], y1) < 6e-3
+        assert rel(yb[b], y1) < 6e-3 and rel(yb[b], ref[b]) < 6e-3, b
+
+
+@pytest.mark.parametrize("nb", [1, 3, 4])
+def test_gemv_mfma_form_at_small_batches(ops, nb):
+    """The MFMA form is selected from 5 sequences up; by knob it also serves 1 - 4 (same results within rounding), and the
+    predicated-load variant of the kernel gives bit-identical results to the predicate-free one at K = 4096 (ragged N)."""
+    from seedstory import _lib
+    dtype, N, K = torch.bfloat16, 4096 + 40, 4096
+    w = dev(synth.normal_like(77, (N, K), 0.05, dtype=dtype))
+    x = dev(synth.normal_like(78, (nb, K), 1.0, dtype=dtype))
+    res = dev(synth.normal_like(79, (nb, N), 1.0, dtype=dtype))
+    nw = dev(synth.normal_like(80, (K,), 0.1, 1.0, dtype=dtype))
+    want = ops.gemv_batched(w, x, norm_w=nw, eps=1e-5, residual=res)
+    _lib.set_tuning("gemv_mfma_min_nb", 1)
+    try:
+        got = ops.gemv_batched(w, x, norm_w=nw, eps=1e-5, residual=res)
+        _lib.set_tuning("gemv_mfma_generic", 1)
+        got_generic = ops.gemv_batched(w, x, norm_w=nw, eps=1e-5, residual=res)
+    finally:
+        _lib.set_tuning("gemv_mfma_min_nb", 5)
+        _lib.set_tuning("gemv_mfma_generic", 0)
+    assert rel(got, want) < 4e-3 and torch.equal(got, got_generic)
 
 
 GEMM_SHAPES = [(1, 64, 64), (37, 100, 256), (65, 4096, 4096), (114, 1000, 4096), (343, 768, 512),
