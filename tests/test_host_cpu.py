@@ -619,7 +619,7 @@ def test_llm_generate_assembles_block_and_sequential_runs_identically(monkeypatc
 def test_splitk_plan_and_bench_slot_groups():
     """Host-only logic of round 3: (1) the split-K plan of the small-M LLaMA projections (ss_gemm_splitk_workspace_bytes is
     pure host code: S slices of M x N fp32; 0 = the regular tiles) — it splits where the column count leaves most CUs
-    idle (N = 4096) and nowhere else; (2) bench.py's decode groups for more than 4 stories per GPU."""
+    idle (N = 4096) and nowhere else; (2) bench.py's decode groups (<= 8 slots per engine since round 4)."""
     from seedstory import _lib
     f = _lib.lib().ss_gemm_splitk_workspace_bytes
     H, I = 4096, 11008
@@ -630,4 +630,5 @@ def test_splitk_plan_and_bench_slot_groups():
     assert f(264, H, 512) == 0 and f(264, 100, H) == 0                                    # short K / ragged N: regular path
     sys.path.insert(0, ROOT)
     import bench
-    assert [bench.slot_groups(n) for n in (1, 2, 3, 4, 6, 8)] == [[1], [2], [3], [4], [3, 3], [4, 4]]
+    assert [bench.slot_groups(n) for n in (1, 2, 3, 4, 6, 8, 9, 16)] == [[1], [2], [3], [4], [6], [8], [5, 4], [8, 8]]
+    assert [bench.slot_groups(n, 4) for n in (4, 6, 8)] == [[4], [3, 3], [4, 4]]         # the round-3 grouping (--max-slots 4)
