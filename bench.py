@@ -388,7 +388,7 @@ MAX_SLOTS = 8       # sequence slots of one engine = stories sharing one sweep o
 
 def slot_groups(spg, max_slots=None):
     """Stories per GPU -> sizes of the lock-step decode groups (an engine sweeps the weights once per token for <= 8 slots:
-    1 - 4 through the dot-product GEMV, 5 - 8 through the MFMA form)."""
+    1 - 2 through the dot-product GEMV, 3 - 8 through the MFMA form)."""
     m = max_slots or MAX_SLOTS
     n = (spg + m - 1) // m
     return [spg // n + (1 if g < spg % n else 0) for g in range(n)]
@@ -511,18 +511,14 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         prof = eng.profile_decode(8)
         # dominant kernel = the decode weight-streaming GEMV.  With <= 2 slots per sweep the K=hidden projections
         # (qkv, o, gate|up per layer + lm_head: 97 launches/token) are ss::gemv_kernel<bf16,8,2,NB> and the down
-        # projection a different symbol; with 3-4 slots every projection runs ss::gemv_ldsx_kernel<bf16,2,NB>
-        # (129 launches/token), so the launch average is taken over all of them.
-        # With 5-8 slots the K=hidden projections run ss::gemv_mfma_kernel (v_mfma_f32_16x16x32, 8 waves = 8 K slices of a
-        # 16-row tile); the 11008-deep down projection is swept once per half of the slots by gemv_ldsx_kernel.
+        # projection a different symbol.
+        # With 3-8 slots every projection runs ss::gemv_mfma_exact_kernel (v_mfma_f32_16x16x32, 8 waves = 8 K slices of a
+        # 16-row tile; the 11008-deep down projection in the packed 43-step form): 129 launches/token, averaged together.
         if GRP <= 2:
             kern = "gemv_kernel<bf16_t,8,2,%d>" % GRP
             n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
-        elif GRP > 4:
-            kern = "gemv_mfma_kernel<bf16_t>"
-            n_launch, tot_bytes, tot_ms = prof["gemv_launches"], prof["gemv_bytes"], prof["gemv_ms"]
         else:
-            kern = "gemv_ldsx_kernel<bf16_t,2,%d>" % GRP
+            kern = "gemv_mfma_exact_kernel<bf16_t>"
             n_launch = prof["gemv_launches"] + prof["gemv_down_launches"]
             tot_bytes = prof["gemv_bytes"] + prof["gemv_down_bytes"]
             tot_ms = prof["gemv_ms"] + prof["gemv_down_ms"]
@@ -543,8 +539,14 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
                 except Exception:
                     pmcj = {}
         if pmcj.get("stories_per_gpu") == GRP:      # counters were collected at this many slots per sweep
-            traffic = pmcj.get("gemv_hbm_traffic", {}).get(kern, {}).get("hbm_bytes_per_launch")
-            under_render_us = pmcj.get("gemv_avg_us_under_render", {}).get(kern)
+            # (the MFMA form is several template instances — plain | SiLU pair, 16 | 43 steps: dispatch-weighted mean)
+            base = kern.split("<")[0]
+            recs = [v for k, v in pmcj.get("gemv_hbm_traffic", {}).items() if k.split("<")[0] == base and v.get("dispatches")]
+            if recs:
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in recs) / sum(v["dispatches"] for v in recs))
+            us = [v for k, v in pmcj.get("gemv_avg_us_under_render", {}).items() if k.split("<")[0] == base]
+            if us:
+                under_render_us = round(sum(us) / len(us), 3)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel": "ss::" + kern, "slots_per_sweep": GRP,
@@ -585,13 +587,22 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
             return tot / reps
         layer_w_bytes = NL * (3 * H * H + H * H + 2 * INTER * H + H * INTER) * 2
         blk_ms = timed_prefill(66, 343 + CAPTION)
+        blk_flops = GRP * 66 * (2.0 * layer_w_bytes / 2 + 4.0 * NL * H * (343 + CAPTION + 33))   # projections + attention
+        hbm_floor, mfma_floor = layer_w_bytes / 8e12, blk_flops / 2.5e15
         roof["block_continuation"] = {
             "what": "the 65 processor-forced image tokens of a story step: %d slots x 66 rows as one stacked forward" % GRP,
-            "bound": "hbm", "rows": GRP * 66, "ms": round(blk_ms, 3), "weight_bytes": layer_w_bytes,
+            "bound": "hbm" if hbm_floor >= mfma_floor else "mfma", "rows": GRP * 66, "ms": round(blk_ms, 3),
+            "weight_bytes": layer_w_bytes, "flops": blk_flops,
+            "hbm": {"achieved": round(layer_w_bytes / (blk_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(layer_w_bytes / (blk_ms * 1e-3) / 8e12, 4)},
+            "mfma": {"achieved": round(blk_flops / (blk_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(blk_flops / (blk_ms * 1e-3) / 2.5e15, 4)},
             "achieved": round(layer_w_bytes / (blk_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(layer_w_bytes / (blk_ms * 1e-3) / 8e12, 4),
             "note": "algorithmic bytes = the 32 layers' weights once (lm_head on the last rows excluded); per story step "
-                    "this replaces 65 of the 115 decode iterations"}
+                    "this replaces 65 of the 115 decode iterations.  The ridge of the chip (2.5 PFLOP/s / 8 TB/s = 312 flop/B) "
+                    "is at 312 stacked rows: 4 slots (264 rows) are HBM-bound, 8 slots (528 rows) MFMA-bound — `bound` names "
+                    "the larger floor, both fractions are given; achieved/frac at the top level stay the HBM ones"}
         S_big = prompt_len(STORY_LEN - 1)
         pf_ms = timed_prefill(S_big, 0, reps=2)
         pf_flops = GRP * S_big * (2.0 * layer_w_bytes / 2 + 4.0 * NL * H * (S_big + 1) / 2)   # projections + causal attention
@@ -810,7 +821,7 @@ def main():
                          "with 4 — the batch-16 UNet forward costs 59.0 ms per 8 samples against 61.1), 4 for the slot ring")
     ap.add_argument("--max-slots", type=int, default=0,
                     help="sequence slots per decode engine (stories sharing one sweep of the weights per token): 1..8; "
-                         "default 8 (5 - 8 slots decode through the MFMA form of the GEMV)")
+                         "default 8 (3 - 8 slots decode through the MFMA form of the GEMV)")
     ap.add_argument("--render-groups", type=int, default=0,
                     help="render the round's images as this many independent batches on separate HIP streams at once (de-tokenizer "
                          "replicas over equal weights); default 1.  Measured with 8 resident stories: 2 groups of 4 = 1.955 story-steps/s, one "

@@ -215,6 +215,16 @@ int ss_attention(const void* q, const void* k, const void* v, void* out, int64_t
                  int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, int causal_br, int dtype,
                  void* stream);
 
+/* The same with one key count PER batch element (host array of `batch` <= 8 ints; strides as above): the stacked forward
+ * of several story slots whose caches hold different lengths — query rows [b*q_len, (b+1)*q_len) of slot b attend to the
+ * first host_kv_lens[b] entries of slot b's cache, bottom-right causal per slot (modeling_llama_xformer.py:289-295 run
+ * once per story by the reference; LlamaEngine.prefill_batch issues ONE launch for the group). */
+int ss_attention_ragged(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t n_heads,
+                        int64_t q_len, const int32_t* host_kv_lens, int64_t hd, int64_t q_sb, int64_t q_sh, int64_t q_ss,
+                        int64_t k_sb, int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                        int64_t o_sb, int64_t o_sh, int64_t o_ss, float scale, int causal_br, int dtype,
+                        void* stream);
+
 /* Single-query decode attention over the KV cache (q_len = 1 case of :289-295), split-KV.
  * q [n_heads*hd]; caches [n_heads, cache_cap, hd]; kv_len read on the device from
  * *kv_len_dev (so the launch can be replayed from a hipGraph); out [n_heads*hd].

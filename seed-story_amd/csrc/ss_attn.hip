@@ -28,6 +28,8 @@ struct AttnArgs {
     float scale;
     int causal_br;
     int xcd_heads;   // flash_attn3: > 0 = XCD-aware 1-D grid, value = query blocks per head
+    int ragged;      // 1 = batch element b attends to kv_len_b[b] keys (kv_len = their maximum); batch <= 8
+    int kv_len_b[8];
 };
 
 template <typename T> struct AttnMma;
@@ -61,13 +63,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.n_heads, h = bh % a.n_heads;
+    const int kvl = a.ragged ? a.kv_len_b[b] : a.kv_len;      // per-batch key count (stacked story slots)
     const int q0 = blockIdx.x * kBQ;
     const int qi = q0 + wid * 16 + l15;  // this lane's query row
     const int hd = a.hd;
     const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
     const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
     const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
-    const int shift = a.kv_len - a.q_len;  // bottom-right alignment
+    const int shift = kvl - a.q_len;  // bottom-right alignment
 
     // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel ----------------
     // bf16/f16: qf[ks] = Q[qi][ks*32 + grp*8 .. +8];  f32: qs[kk] = Q[qi][kk*4 + grp]
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
     for (int i = 0; i < NDB; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f, l_run = 0.f;
 
-    int kv_end = a.kv_len;
+    int kv_end = kvl;
     if (a.causal_br) {
         const int lim = q0 + kBQ - 1 + shift + 1;  // one past the last key any row of this block sees
         if (lim < kv_end) kv_end = lim;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
         for (int p = tid; p < kBKV * PPR; p += 256) {
             const int key = p / PPR, c = p % PPR, d = c * V;
             const int kg = t0 + key;
-            const bool ok = kg < a.kv_len && d < hd;
+            const bool ok = kg < kvl && d < hd;
             const uint4 kk = ok ? ld16(kp + (int64_t)kg * a.k_ss + d) : make_uint4(0, 0, 0, 0);
             st16(Ks + key * KS + d, kk);
             const uint4 vv = ok ? ld16(vp + (int64_t)kg * a.v_ss + d) : make_uint4(0, 0, 0, 0);
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kg = t0 + kb * 16 + grp * 4 + r;
-                const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi + shift);
+                const bool ok = kg < kvl && (!a.causal_br || kg <= qi + shift);
                 msk[kb][r] = ok;
                 const float sv = ok ? s[kb][r] * a.scale : -1e30f;
                 s[kb][r] = sv;
@@ -264,12 +267,13 @@ void flash_attn2_kernel(const AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, grp = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.n_heads, h = bh % a.n_heads;
+    const int kvl = a.ragged ? a.kv_len_b[b] : a.kv_len;      // per-batch key count (stacked story slots)
     const int q0 = blockIdx.x * BQ2;
     const int hd = a.hd;
     const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
     const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
     const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
-    const int shift = a.kv_len - a.q_len;
+    const int shift = kvl - a.q_len;
     const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void2_t*)smem_raw);
     const float sl2 = a.scale * 1.4426950408889634f;   // scores kept in the log2 domain
@@ -292,7 +296,7 @@ void flash_attn2_kernel(const AttnArgs a) {
         for (int i = 0; i < NDB; ++i) o[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
-    int kv_end = a.kv_len;
+    int kv_end = kvl;
     if (a.causal_br) {
         const int lim = q0 + BQ2 - 1 + shift + 1;
         if (lim < kv_end) kv_end = lim;
@@ -310,8 +314,8 @@ void flash_attn2_kernel(const AttnArgs a) {
             const int key = (wid * IPW + i) * KPI + skey;       // key row inside the tile
             const int kg = t * kBKV + key;
             const int lc = spc ^ (key & (CPR - 1));               // K: swizzled on the source side
-            const bool okk = kg < a.kv_len && lc * V < hd;
-            const bool okv = kg < a.kv_len && spc * V < hd;
+            const bool okk = kg < kvl && lc * V < hd;
+            const bool okv = kg < kvl && spc * V < hd;
             const T* ks = okk ? kp + (int64_t)kg * a.k_ss + lc * V : zero;
             const T* vs = okv ? vp + (int64_t)kg * a.v_ss + spc * V : zero;
             const uint32_t roff = (uint32_t)((wid * IPW + i) * KPI * ROWB);
@@ -361,7 +365,7 @@ void flash_attn2_kernel(const AttnArgs a) {
         // full tiles take a mask-free path, exp2 is the raw v_exp_f32 (arguments <= 0: no range fix-up
         // needed).
         uint4 pfrag[2][NKB / 2];
-        const bool need_mask = a.causal_br || (t0 + kBKV > a.kv_len);   // wave-uniform
+        const bool need_mask = a.causal_br || (t0 + kBKV > kvl);   // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             // running max m_run is kept in RAW score units; p = exp2(s*sl2 - m*sl2) is one FMA + v_exp_f32
@@ -372,7 +376,7 @@ void flash_attn2_kernel(const AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kg = t0 + kb * 16 + grp * 4 + r;
-                        const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
+                        const bool ok = kg < kvl && (!a.causal_br || kg <= qi[qb] + shift);
                         const float sv = ok ? s[qb][kb][r] : -1e30f;
                         s[qb][kb][r] = sv;
                         tmax = fmaxf(tmax, sv);
@@ -510,12 +514,13 @@ void flash_attn3_kernel(const AttnArgs a) {
         bh = blockIdx.y; qblk = blockIdx.x;
     }
     const int b = bh / a.n_heads, h = bh % a.n_heads;
+    const int kvl = a.ragged ? a.kv_len_b[b] : a.kv_len;      // per-batch key count (stacked story slots)
     const int q0 = qblk * BQ2;
     const int hd = a.hd;
     const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
     const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
     const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
-    const int shift = a.kv_len - a.q_len;
+    const int shift = kvl - a.q_len;
     const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void2_t*)smem_raw);
     const float sl2 = a.scale * 1.4426950408889634f;   // scores kept in the log2 domain
@@ -542,7 +547,7 @@ void flash_attn3_kernel(const AttnArgs a) {
     float m_run[2] = {-1e30f, -1e30f};
     const uint4 ones = make_uint4(OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair);
 
-    int kv_end = a.kv_len;
+    int kv_end = kvl;
     if (a.causal_br) {
         const int lim = q0 + BQ2 - 1 + shift + 1;
         if (lim < kv_end) kv_end = lim;
@@ -565,8 +570,8 @@ void flash_attn3_kernel(const AttnArgs a) {
             const int kg = t * kBKV + key;
             const int lc = spc ^ (key & (CPR - 1));               // K: 16-byte chunks swizzled on the source side
             const int lv = ((((spc >> 1) ^ vsw(key)) << 1) | (spc & 1));   // V: 32-byte chunks
-            const bool okk = kg < a.kv_len && lc * V < hd;
-            const bool okv = kg < a.kv_len && lv * V < hd;
+            const bool okk = kg < kvl && lc * V < hd;
+            const bool okv = kg < kvl && lv * V < hd;
             const T* ks = okk ? kp + (int64_t)kg * a.k_ss + lc * V : zero;
             const T* vs = okv ? vp + (int64_t)kg * a.v_ss + lv * V : zero;
             const uint32_t roff = (uint32_t)((wid * IPW + i) * KPI * ROWB);
@@ -617,7 +622,7 @@ void flash_attn3_kernel(const AttnArgs a) {
         }
         // ---- softmax numerators (log2 domain, deferred rescale) ----------------------------------------
         uint4 pfrag[2][NKB / 2];
-        const bool need_mask = a.causal_br || (t0 + kBKV > a.kv_len);   // wave-uniform
+        const bool need_mask = a.causal_br || (t0 + kBKV > kvl);   // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (need_mask) {
@@ -626,7 +631,7 @@ void flash_attn3_kernel(const AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kg = t0 + kb * 16 + grp * 4 + r;
-                        const bool ok = kg < a.kv_len && (!a.causal_br || kg <= qi[qb] + shift);
+                        const bool ok = kg < kvl && (!a.causal_br || kg <= qi[qb] + shift);
                         s[qb][kb][r] = ok ? s[qb][kb][r] : -1e30f;
                     }
             }
@@ -1058,7 +1063,33 @@ int ss_attention(const void* q, const void* k, const void* v, void* out, int64_t
     a.q_len = (int)q_len; a.kv_len = (int)kv_len; a.hd = (int)hd; a.n_heads = (int)n_heads;
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_sh = o_sh; a.o_ss = o_ss;
-    a.scale = scale; a.causal_br = causal_br; a.xcd_heads = 0;
+    a.scale = scale; a.causal_br = causal_br; a.xcd_heads = 0; a.ragged = 0;
+    return attention_dev(a, batch, dtype, (hipStream_t)stream);
+}
+
+// The same with a key count PER batch element (host array, batch <= 8): the stacked forward of several story slots
+// whose caches hold different lengths (LlamaEngine.prefill_batch), one launch instead of one per slot.
+int ss_attention_ragged(const void* q, const void* k, const void* v, void* out, int64_t batch, int64_t n_heads, int64_t q_len,
+                        const int32_t* host_kv_lens, int64_t hd, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                        int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb, int64_t o_sh,
+                        int64_t o_ss, float scale, int causal_br, int dtype, void* stream) {
+    SS_REQUIRE(host_kv_lens && batch >= 1 && batch <= 8, "attention_ragged: 1..8 batch elements");
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out;
+    a.q_len = (int)q_len; a.hd = (int)hd; a.n_heads = (int)n_heads;
+    a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
+    a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_sh = o_sh; a.o_ss = o_ss;
+    a.scale = scale; a.causal_br = causal_br; a.xcd_heads = 0; a.ragged = 1;
+    int mx = 0;
+    for (int b = 0; b < 8; ++b) {
+        a.kv_len_b[b] = b < batch ? host_kv_lens[b] : 0;
+        if (b < batch) {
+            SS_REQUIRE(host_kv_lens[b] > 0 && (!causal_br || host_kv_lens[b] >= q_len), "attention_ragged: kv_len[%d] = %d", b,
+                       (int)host_kv_lens[b]);
+            if (host_kv_lens[b] > mx) mx = host_kv_lens[b];
+        }
+    }
+    a.kv_len = mx;
     return attention_dev(a, batch, dtype, (hipStream_t)stream);
 }
 

@@ -576,6 +576,39 @@ static int rowstat_cfg(GemmArgs& g, int* bn, int* tn) {
     return cfg;
 }
 
+// Fallback producer of the RSTAT / rowpart statistics for shapes no statistics tile takes: one wave per stored row of C.
+//   stat != null:  stat[m] += (sum, sum of squares) of the row            (the accumulator form, fp64)
+//   part != null:  part[(m * part_ld + strip) * 2 ..] = the strip's sums    (strips of `tn` columns, fp32 like the epilogue's)
+template <typename T>
+__global__ __launch_bounds__(256) void rowstat_fallback_kernel(const T* __restrict__ C, int64_t ldc, int M, int N, double* __restrict__ stat,
+                                                               float* __restrict__ part, int part_ld, int tn) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const T* row = C + (int64_t)m * ldc;
+    double t1 = 0.0, t2 = 0.0;
+    for (int n0 = 0, strip = 0; n0 < N; n0 += tn, ++strip) {
+        float s1 = 0.f, s2 = 0.f;
+        const int n1 = n0 + tn < N ? n0 + tn : N;
+        for (int n = n0 + lane; n < n1; n += 64) {
+            const float v = Tr<T>::ld(row + n);
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (part && lane == 0 && strip < part_ld) {
+            part[((int64_t)m * part_ld + strip) * 2] = s1;
+            part[((int64_t)m * part_ld + strip) * 2 + 1] = s2;
+        }
+        t1 += (double)s1;
+        t2 += (double)s2;
+    }
+    if (stat && lane == 0) {
+        stat[(int64_t)m * 2] += t1;
+        stat[(int64_t)m * 2 + 1] += t2;
+    }
+}
+
 template <typename T>
 int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                 int64_t ldc, const void* bias, const void* residual, int64_t ldr, int epi, hipStream_t s,
@@ -615,10 +648,20 @@ int gemm_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int
                 g.rowpart = rowpart;
                 g.rowpart_ld = (int)(N / tn);
             }
-            const int rc = gemm_sp_dispatch<T>(cfg + 200, g, s);
+            const bool force_fb = tuning_get("gemm_rowstat_fallback", 0) != 0;      // (tests)
+            int rc = force_fb ? 1 : gemm_sp_dispatch<T>(cfg + 200, g, s);
+            if (rc == 1 && !rowpart && !force_fb) rc = gemm_sp_dispatch<T>(265, g, s);       // the 128x128 staged tile takes more shapes
             if (rc == 1) {
-                set_error("ss_gemm_rowstat: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 200, (long long)M, (long long)N, (long long)K);
-                return SS_EINVAL;
+                // no statistics tile for this shape / alignment (a choice ss_gemm itself would have run on the double-buffered
+                // kernel): the plain GEMM, then one pass over the stored rows that produces the same sums
+                g.rowstat_out = nullptr;
+                g.rowpart = nullptr;
+                rc = gemm_dispatch_cfg<T>(lookup_cfg<T>(g), g, s);
+                if (rc) return rc;
+                hipLaunchKernelGGL(rowstat_fallback_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)C, ldc, (int)M,
+                                   (int)N, rowstat_out, rowpart, rowpart ? (int)(N / tn) : 0, tn > 0 ? tn : (int)N);
+                SS_LAUNCH_CHECK("rowstat_fallback");
+                return SS_OK;
             }
             return rc;
         }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(const GemvArgs a) {
     }
 }
 
-// ---- MFMA form: 5..16 sequences per sweep (16-bit types, K <= 4096) ----------------------------------------------------
+// ---- MFMA form: 3..16 sequences per sweep (16-bit types, K <= 4096 or K = 11008) ----------------------------------------------------
 // Past 4 sequences the dot-product kernels above run out of VALU / LDS rate (8 sequences = 8 v_dot2 per 4 weight bytes
 // plus 8 LDS reads per pack), while one v_mfma_f32_16x16x32 consumes 1 KB of weights for up to SIXTEEN sequences in 8
 // passes: the matrix core turns the batched decode projection back into a pure weight stream.
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvArgs a, const 
             const T* p = W + ((int64_t)row + (int64_t)m * N) * K + k0;
             gv_static_for<NS>([&](auto s_) {
                 constexpr int s = decltype(s_)::value;
-                wa[m][s] = s < nvalid ? ld_nt16(p + s * 32) : make_uint4(0, 0, 0, 0);
+                wa[m][s] = s < nvalid ? ld16(p + s * 32) : make_uint4(0, 0, 0, 0);
             });
         }
         gv_static_for<NS>([&](auto s_) {
@@ -542,9 +542,8 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvArgs a, const 
 // their step comes up: 88 VGPRs.  (Columns 8..15 of D then hold garbage that is never stored.)  No RMSNorm in this form.
 __device__ __forceinline__ void gv_fence(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-template <bool SHR>
 __device__ __forceinline__ uint4 gv_row_shift8(const uint4& v) {
-    constexpr int ctrl = SHR ? 0x118 : 0x108;      // row_shr:8 | row_shl:8
+    constexpr int ctrl = 0x108;                    // row_shl:8: lane l of a 16-lane row reads lane l + 8
     uint4 r;
     r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, ctrl, 0xf, 0xf, true);
     r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, ctrl, 0xf, 0xf, true);
@@ -553,7 +552,7 @@ __device__ __forceinline__ uint4 gv_row_shift8(const uint4& v) {
     return r;
 }
 
-template <typename T, bool SILU, int SPW, bool NT, bool SHR = false>
+template <typename T, bool SILU, int SPW, bool NT>
 __global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, const int ntiles) {
     constexpr int CH = kGvChunk, M = SILU ? 2 : 1;
     constexpr int NCH = (SPW + CH - 1) / CH;
@@ -672,7 +671,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, 
                     uint4 b;
                     if constexpr (!PACK) b = xf[s];
                     else if constexpr (s < HALF) b = xf[s];
-                    else b = gv_row_shift8<SHR>(xf[s - HALF]);
+                    else b = gv_row_shift8(xf[s - HALF]);
 #pragma unroll
                     for (int m = 0; m < M; ++m) acc[m] = gv_mfma<T>(wa[c & 1][m][e], b, acc[m]);
                 }
@@ -705,18 +704,20 @@ static int gemv_launch_mfma(const GemvArgs& a, hipStream_t s) {
     const int rounds = cdiv(ntiles, cus);
     const int blocks = cdiv(ntiles, rounds);
     const bool generic = tuning_get("gemv_mfma_generic", 0) != 0;
+    // plain loads, not non-temporal ones: a fragment load touches HALF a 128-byte line per row and the next instruction the
+    // other half; measured on the five LLaMA-7B shapes at 8 sequences, nt is 3 - 13 % slower (lm_head 52.0 vs 46.2 us)
+    const bool nt = tuning_get("gemv_mfma_nt", 0) != 0;
     const dim3 g((unsigned)blocks), b(512);
 #define SS_GV_EXACT(SPW)                                                                                                  \
     do {                                                                                                                  \
-        if (silu) { if (a.use_nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, true, SPW, true>), g, b, 0, s, a, ntiles); \
+        if (silu) { if (nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, true, SPW, true>), g, b, 0, s, a, ntiles);      \
                     else hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, true, SPW, false>), g, b, 0, s, a, ntiles); }       \
-        else { if (a.use_nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, SPW, true>), g, b, 0, s, a, ntiles);     \
+        else { if (nt) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, SPW, true>), g, b, 0, s, a, ntiles);          \
                else hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, SPW, false>), g, b, 0, s, a, ntiles); }           \
     } while (0)
     if (!generic && a.K == kGvWaves * kGvSteps * 32) SS_GV_EXACT(16);
     else if (!generic && a.K == kGvWaves * 43 * 32) {
-        if (tuning_get("gemv_mfma_dpp_shr", 0) && !silu) hipLaunchKernelGGL((gemv_mfma_exact_kernel<T, false, 43, true, true>), g, b, 0, s, a, ntiles);
-        else SS_GV_EXACT(43);
+        SS_GV_EXACT(43);
     }
     else if (silu) hipLaunchKernelGGL((gemv_mfma_kernel<T, true>), g, b, 0, s, a, spw, ntiles);
     else hipLaunchKernelGGL((gemv_mfma_kernel<T, false>), g, b, 0, s, a, spw, ntiles);
@@ -788,9 +789,12 @@ int gemv_launch(const GemvArgs& a0, hipStream_t s) {
     SS_REQUIRE(!(epi & SS_EPI_GELU), "gemv: GELU epilogue not supported");
     SS_REQUIRE(a.nb >= 1 && a.nb <= 16, "gemv: batch %d unsupported (1..16)", a.nb);
     a.use_nt = tuning_get("gemv_nt", 1);
-    // 5+ sequences (or fewer, by knob): the MFMA form when the shape allows it (16-bit, 8 waves x 16 steps of 32 cover K)
+    // 3+ sequences (knob): the MFMA form when the shape allows it (16-bit, 8 waves x 16 steps of 32 cover K, or the packed
+    // 11008-deep form).  Measured on the five LLaMA-7B projections (tools/gemv_bench.py, rotating weights, us per launch):
+    // dot-product kernels at 1 | 4 sequences 20.7 9.9 32.3 19.3 46.1 | 24.4 11.0 39.0 25.7 47.8; MFMA form at 8 sequences
+    // 24.2 9.9 37.3 21.9 46.2 — one sequence stays with the dot-product kernel, 3 and more go through the matrix core.
     if constexpr (V == 8) {
-        if (a.nb >= tuning_get("gemv_mfma_min_nb", 5) && gemv_mfma_eligible<T>(a)) return gemv_launch_mfma<T>(a, s);
+        if (a.nb >= tuning_get("gemv_mfma_min_nb", 3) && gemv_mfma_eligible<T>(a)) return gemv_launch_mfma<T>(a, s);
     }
     if (a.nb > 4) {      // no MFMA form for this shape / type: two sweeps of half the sequences each
         const int h1 = a.nb / 2;

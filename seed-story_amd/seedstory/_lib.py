@@ -90,6 +90,7 @@ PROTOTYPES = {
     "ss_l2normalize_dim1": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, vp]),
     "ss_rope_kv_append": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, C.c_int, vp]),
     "ss_attention": (C.c_int, [vp, vp, vp, vp] + [i64] * 17 + [f32, C.c_int, C.c_int, vp]),
+    "ss_attention_ragged": (C.c_int, [vp, vp, vp, vp] + [i64] * 3 + [vp] + [i64] * 13 + [f32, C.c_int, C.c_int, vp]),
     "ss_attn_decode_workspace_bytes": (sz, [i64, i64]),
     "ss_attn_decode": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "ss_gemm": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, C.c_int, C.c_int, vp]),

@@ -141,6 +141,22 @@ def attention_cache(q, kcache, vcache, kv_len, causal_br=True):
     return out
 
 
+def attention_cache_slots(q, kcache, vcache, kv_lens, causal_br=True):
+    """Stacked slots: q [S * M, n_heads*hd] (M rows per slot) against caches [S, n_heads, cap, hd]; slot b attends to its
+    first kv_lens[b] entries (ss_attention_ragged: one launch for the S slots)."""
+    import ctypes
+    _req(q); _req(kcache)
+    S, n_heads, cap, hd = kcache.shape
+    E = n_heads * hd
+    M = q.shape[0] // S
+    out = torch.empty_like(q)
+    lens = (ctypes.c_int32 * S)(*[int(x) for x in kv_lens])
+    check(lib().ss_attention_ragged(p(q), p(kcache), p(vcache), p(out), S, n_heads, M, ctypes.cast(lens, ctypes.c_void_p), hd,
+                                    M * E, hd, E, n_heads * cap * hd, cap * hd, hd, n_heads * cap * hd, cap * hd, hd, M * E, hd, E,
+                                    1.0 / math.sqrt(hd), int(causal_br), dt(q), stream()), "ss_attention_ragged")
+    return out
+
+
 def attn_decode(q, kcache, vcache, kv_len_dev):
     _req(q); _req(kcache)
     n_heads, cap, hd = kcache.shape

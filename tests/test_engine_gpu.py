@@ -591,6 +591,46 @@ def test_prefill_batch_equals_per_slot_prefill(golden, dtype, tol, stack_rows):
         assert rel(e4.k_cache[:, :, :n], ref.k_cache[:, :, :n]) < tol and rel(e4.v_cache[:, :, :n], ref.v_cache[:, :, :n]) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("n_seq", [3, 8])
+def test_prefill_batch_uniform_rows_one_attention_launch(golden, dtype, tol, n_seq):
+    """The lock-step image-token block: every slot feeds the SAME number of rows against caches of DIFFERENT lengths — the
+    stacked forward then issues one ragged attention launch per layer (ss_attention_ragged) instead of one per slot; results
+    equal the per-slot engine, and equal the per-slot-launch path of the same engine bit for bit (knob llama_batched_attn)."""
+    from seedstory import _lib
+    from seedstory.llama import LlamaEngine
+    g, meta = golden
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"], dtype=dtype)
+    kw = dict(hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"], dtype=dtype,
+              device=DEV, cache_cap=256, max_new=128, img_ids=_img_ids(meta))
+    emb = wd["model.embed_tokens.weight"]
+    lens = [37, 21, 30, 9, 50, 44, 12, 26][:n_seq]
+    prompts = [synth.randint(930 + b, (lens[b],), 3, 250) for b in range(n_seq)]
+    conts = [synth.randint(940 + b, (66,), 3, 250) for b in range(n_seq)]
+    outs = []
+    for batched in (1, 0):
+        _lib.set_tuning("llama_batched_attn", batched)
+        try:
+            e = LlamaEngine(wd, max_prefill_rows=66 * n_seq, n_seq=n_seq, **kw)
+            e.prefill_batch([emb[p] for p in prompts])
+            hc = e.prefill_batch([emb[c] for c in conts], want_hidden=True)
+            outs.append((e, hc))
+        finally:
+            _lib.set_tuning("llama_batched_attn", 1)
+    for b in range(n_seq):
+        ref = LlamaEngine(wd, max_prefill_rows=128, **kw)
+        ref.prefill(emb[prompts[b]])
+        h2 = ref.prefill(emb[conts[b]], want_hidden=True)
+        n = lens[b] + 66
+        for e, hc in outs:
+            e.select(b)
+            assert e.lengths() == ref.lengths() == (n, n)
+            assert rel(hc[b], h2) < tol and rel(e.logits, ref.logits) < tol
+            assert rel(e.k_cache[:, :, :n], ref.k_cache[:, :, :n]) < tol
+        assert torch.equal(outs[0][1][b], outs[1][1][b])
+
+
 class _ProcStub:
     """Carries the 66 image-token ids the way AutoImageTokenGenerationProcessor does (generation.py:17)."""
 

@@ -137,9 +137,10 @@ def test_gemv_silu_mul(ops, I, K, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemv_batched_rows_match_single(ops, nb, N, K, dtype):
     """Lock-step decode of nb story slots: row b of the batched sweep == the batch-1 kernel on row b
-    (same per-lane summation order in the register path; LDS-staged path within rounding).  nb >= 5 in a 16-bit type with
-    K <= 4096 is the MFMA form (K = 4096: the predicate-free stream loop; K = 256 / 1664 and N = 1000: predicated loads,
-    ragged last row tile); fp32 and K = 11008 sweep the weights once per half of the sequences."""
+    (same per-lane summation order in the register path; LDS-staged path within rounding).  nb >= 3 in a 16-bit type with
+    K <= 4096 or K = 11008 (nb <= 8) is the MFMA form (K = 4096: the predicate-free stream loop; K = 256 / 1664 and N = 1000: predicated loads,
+    ragged last row tile; K = 11008: the packed 43-step form up to 8 sequences); fp32, and K = 11008 at 16 sequences, sweep
+    the weights once per half of the sequences."""
     w = dev(synth.normal_like(70, (N, K), 0.05, dtype=dtype))
     x = dev(synth.normal_like(71, (nb, K), 1.0, dtype=dtype))
     res = dev(synth.normal_like(72, (nb, N), 1.0, dtype=dtype))
@@ -183,7 +184,7 @@ def test_gemv_batched_silu(ops, nb, I, K, dtype):
 
 @pytest.mark.parametrize("nb", [1, 3, 4])
 def test_gemv_mfma_form_at_small_batches(ops, nb):
-    """The MFMA form is selected from 5 sequences up; by knob it also serves 1 - 4 (same results within rounding), and the
+    """The MFMA form is selected from 3 sequences up; by knob it also serves 1 - 4 (same results within rounding), and the
     predicated-load variant of the kernel gives bit-identical results to the predicate-free one at K = 4096 (ragged N)."""
     from seedstory import _lib
     dtype, N, K = torch.bfloat16, 4096 + 40, 4096
@@ -198,7 +199,7 @@ def test_gemv_mfma_form_at_small_batches(ops, nb):
         _lib.set_tuning("gemv_mfma_generic", 1)
         got_generic = ops.gemv_batched(w, x, norm_w=nw, eps=1e-5, residual=res)
     finally:
-        _lib.set_tuning("gemv_mfma_min_nb", 5)
+        _lib.set_tuning("gemv_mfma_min_nb", 3)
         _lib.set_tuning("gemv_mfma_generic", 0)
     assert rel(got, want) < 4e-3 and torch.equal(got, got_generic)
 
@@ -385,6 +386,25 @@ def test_attention_cache_matches_decode(ops):
     a = ops.attention_cache(q, kc, vc, kv, causal_br=True)
     b = ops.attn_decode(q[0].contiguous(), kc, vc, torch.tensor([kv], dtype=torch.int32, device=DEV))
     assert rel(a[0], b) < 1e-2
+
+
+@pytest.mark.parametrize("dtype,M,hd", [(torch.bfloat16, 66, 128), (torch.bfloat16, 20, 128), (torch.bfloat16, 130, 64),
+                                        (torch.float32, 66, 128), (torch.float16, 40, 128)])
+def test_attention_ragged_slots_equal_per_slot_launches(ops, dtype, M, hd):
+    """ss_attention_ragged (one launch, slot b attends to its own kv_lens[b] cache entries, bottom-right causal per slot)
+    == one ss_attention launch per slot, bit for bit: every flash kernel variant (q_len < 32 | >= 32, head dim 64 | 128)."""
+    S, H, cap = 5, 4, 320
+    lens = [M, 300, M + 1, 257, max(M, 129)]
+    q = dev(synth.normal_like(40, (S * M, H * hd), 1.0, dtype=dtype))
+    kc = dev(synth.normal_like(41, (S, H, cap, hd), 1.0, dtype=dtype))
+    vc = dev(synth.normal_like(42, (S, H, cap, hd), 1.0, dtype=dtype))
+    got = ops.attention_cache_slots(q, kc, vc, lens)
+    for b in range(S):
+        want = ops.attention_cache(q[b * M:(b + 1) * M].contiguous(), kc[b], vc[b], lens[b], causal_br=True)
+        assert torch.equal(got[b * M:(b + 1) * M], want), b
+    from seedstory import _lib
+    with pytest.raises(_lib.SSError):
+        ops.attention_cache_slots(q, kc, vc, [M - 1] + lens[1:])          # causal: a slot needs kv_len >= q_len
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -161,6 +161,37 @@ def test_gemm_rowpart_partials_and_folded_consumer(M, N, K, res):
     assert e < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(2048 + 77, 1280, 1280), (1000, 640, 640)])
+def test_gemm_rowstat_fallback_pass_matches_epilogue_statistics(M, N, K):
+    """a shape / alignment no statistics tile takes must not fail ss_gemm_rowstat — the plain GEMM runs and one pass
+    over the stored rows produces the same sums (`gemm_rowstat_fallback` forces that path here): accumulator and per-strip
+    partial forms against the epilogue's."""
+    from seedstory import _lib, ops
+    a = synth.normal_like(M + K, (M, K), 1.0).to(BF).to(DEV)
+    w = synth.normal_like(N + K + 1, (N, K), 1.0 / math.sqrt(K)).to(BF).to(DEV)
+    b = (synth.normal_like(7, (N,), 0.3) + 9.0).to(BF).to(DEV)
+    strips = ops.rowpart_strips(M, N, K, BF)
+    acc0 = torch.zeros(M, 2, dtype=torch.float64, device=DEV)
+    part0 = torch.empty(M, strips, 2, dtype=torch.float32, device=DEV)
+    y0 = ops.gemm(a, w, bias=b, rowstat=acc0)
+    ops.gemm(a, w, bias=b, rowpart=part0)
+    _lib.set_tuning("gemm_rowstat_fallback", 1)
+    try:
+        acc1 = torch.zeros_like(acc0)
+        part1 = torch.full_like(part0, float("nan"))
+        y1 = ops.gemm(a, w, bias=b, rowstat=acc1)
+        y2 = ops.gemm(a, w, bias=b, rowpart=part1)
+    finally:
+        _lib.set_tuning("gemm_rowstat_fallback", 0)
+    assert rel(y1, y0) < 2e-3 and rel(y2, y0) < 2e-3
+    yd = y1.double()
+    assert rel(acc1[:, 0], yd.sum(1)) < 1e-6 and rel(acc1[:, 1], (yd * yd).sum(1)) < 1e-6
+    assert rel(acc1, acc0) < 1e-3
+    y2d = y2.double()
+    assert not bool(torch.isnan(part1).any())
+    assert rel(part1[:, :, 0].double().sum(1), y2d.sum(1)) < 1e-6 and rel(part1[:, :, 1].double().sum(1), (y2d * y2d).sum(1)) < 1e-6
+
+
 def test_folded_gemm_every_row_many_launches():
     """Regression (round 4): the folded epilogue on the 4-wave tiles (61 / 65 / 67 / 68 / 70) sporadically returned one wrong
     element per 16-row strip — invisible in a whole-tensor norm (16 bad rows of 32768).  The dispatcher now runs the folded

@@ -16,16 +16,6 @@ NBS = [int(x) for x in os.environ.get("GEMV_NBS", "1,4,8").split(",")]
 SHAPES = [("qkv+norm", 12288, 4096, dict(norm=True)), ("o+res", 4096, 4096, dict(res=True)), ("gate|up+norm silu", 11008, 4096, dict(norm=True, silu=True)),
           ("down+res", 4096, 11008, dict(res=True)), ("lm_head", 32066, 4096, {})]
 out = []
-# which DPP direction hands lanes 8..15 of a row to lanes 0..7 (the packed 43-step form of the down projection)
-_w = torch.randn(4096, 11008, device=dev, dtype=dt) * 0.02
-_x = torch.randn(8, 11008, device=dev, dtype=dt)
-_ref = _x.float() @ _w.float().t()
-for shr in (0, 1):
-    _lib.set_tuning("gemv_mfma_dpp_shr", shr)
-    _y = ops.gemv_batched(_w, _x).float()
-    print(json.dumps({"check": "down K=11008 nb=8", "gemv_mfma_dpp_shr": shr, "rel_err": float((_y - _ref).norm() / _ref.norm())}), flush=True)
-_lib.set_tuning("gemv_mfma_dpp_shr", 0)
-del _w, _x, _ref, _y
 for name, N, K, kw in SHAPES:
     rows = 2 * N if kw.get("silu") else N
     copies = max(2, int(1.2e9 // (rows * K * 2)))
@@ -52,7 +42,7 @@ for name, N, K, kw in SHAPES:
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * copies)
             for k, v in kv:
-                _lib.set_tuning(k, {"gemv_mfma_min_nb": 5, "gemv_nt": 1, "gemv_mfma_blocks": 256}.get(k, 0))
+                _lib.set_tuning(k, {"gemv_mfma_min_nb": 3, "gemv_nt": 1, "gemv_mfma_blocks": 256, "gemv_mfma_nt": 0}.get(k, 0))
             rec = {"shape": name, "N": N, "K": K, "nb": nb, "variant": variant if not kv else dict(kv), "us": round(us, 2),
                    "GBps": round(rows * K * 2 / us / 1e3, 1), "MB": round(rows * K * 2 / 1e6, 1)}
             out.append(rec)

@@ -168,7 +168,13 @@ if mode == "stats":
     json.dump(gem, open(os.path.join(OUT, "round4_gemv_kernel_trace_avg.json"), "w"), indent=1)
     print(json.dumps(gem))
 else:
-    res = {"stories_per_gpu": 4, "tile_table_sha16": table_sha16()}
+    slots = 8
+    try:        # slots per sweep of the --mllm-only command the FETCH_SIZE pass profiled (its JSON line)
+        line = [l for l in open(os.path.join("gpurun_out", "r4_fetch.log")) if l.startswith('{"metric')][-1]
+        slots = int(json.loads(line)["roofline"]["mllm_decode_gemv"]["slots_per_sweep"])
+    except Exception:
+        pass
+    res = {"stories_per_gpu": slots, "tile_table_sha16": table_sha16()}
     try:
         res.update(json.load(open(os.path.join(OUT, "round4_gemv_kernel_trace_avg.json"))))
     except Exception:
