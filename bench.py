@@ -503,12 +503,15 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
     events on the first decode group, and — with a de-tokenizer — the MFMA-bound half (one UNet forward of a render
     group's batch, the dominant ff1 GEGLU GEMM over rotating weights, the fp8 variant)."""
     GRP = eng.n_seq
+    dbg = (lambda m: (torch.cuda.synchronize(), print("ROOF", m, flush=True))) if os.environ.get("SS_ROOF_DEBUG") else (lambda m: None)
+    dbg("start")
     # ---- roofline of the dominant kernel (decode GEMV, HBM-bound), measured live with HIP events ----
     roof = None
     if True:
         for b in range(GRP):
             eng.select(b).set_lengths(343, 343)
         prof = eng.profile_decode(8)
+        dbg("profile_decode done")
         # dominant kernel = the decode weight-streaming GEMV.  With <= 2 slots per sweep the K=hidden projections
         # (qkv, o, gate|up per layer + lm_head: 97 launches/token) are ss::gemv_kernel<bf16,8,2,NB> and the down
         # projection a different symbol.
@@ -587,6 +590,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
             return tot / reps
         layer_w_bytes = NL * (3 * H * H + H * H + 2 * INTER * H + H * INTER) * 2
         blk_ms = timed_prefill(66, 343 + CAPTION)
+        dbg("block done")
         blk_flops = GRP * 66 * (2.0 * layer_w_bytes / 2 + 4.0 * NL * H * (343 + CAPTION + 33))   # projections + attention
         hbm_floor, mfma_floor = layer_w_bytes / 8e12, blk_flops / 2.5e15
         roof["block_continuation"] = {
@@ -605,6 +609,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
                     "the larger floor, both fractions are given; achieved/frac at the top level stay the HBM ones"}
         S_big = prompt_len(STORY_LEN - 1)
         pf_ms = timed_prefill(S_big, 0, reps=2)
+        dbg("prefill done")
         pf_flops = GRP * S_big * (2.0 * layer_w_bytes / 2 + 4.0 * NL * H * (S_big + 1) / 2)   # projections + causal attention
         roof["prompt_prefill"] = {
             "what": "stacked prompt prefill of the %d lock-step stories, S = %d each (the window after step %d)" % (GRP, S_big, WINDOW - 1),

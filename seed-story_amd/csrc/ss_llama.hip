@@ -64,6 +64,8 @@ __global__ __launch_bounds__(1024) void sample_embed_kernel(T* logits, int vocab
     }
     if (st[ST_DONE]) return;
     int tok = imgproc_argmax_block<T>(logits, vocab, st[ST_LAST], img_ids, n_img_ids, sv, si);
+    if ((unsigned)tok >= (unsigned)vocab) tok = 0;     // all-NaN logits have no maximum (torch.argmax: the first NaN): never
+                                                       // index the embedding table with the sentinel
     const int n = st[ST_NGEN];
     if (n < st[ST_NFORCED]) tok = forced[n];
     // ST_EOS packs two stop ids: the EOS token in the low half and an optional second stop token + 1 in the high half
@@ -442,7 +444,10 @@ int ss_llama_create(const ss_llama_config* cfg, const ss_llama_weights* w, void*
     hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipHostMalloc((void**)&h->pinned, (size_t)h->n_seq * 16 * sizeof(int32_t) + 64, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemset(h->state, 0, (size_t)h->n_seq * 8 * sizeof(int32_t));
+    // the whole workspace starts as zeros: a cache row a caller declares valid without having written it (set_lengths on a
+    // fresh slot: profiling runs, KV mirrors) then holds zeros, not the allocator's residue — NaN bit patterns there turn
+    // every logit into NaN
+    if (e == hipSuccess) e = hipMemset(c.base, 0, c.off);
     if (e == hipSuccess && cfg->n_img_ids > 0)
         e = hipMemcpy(h->img_ids, host_img_ids, cfg->n_img_ids * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = check_hip(e, "llama_create"); delete h; return rc; }

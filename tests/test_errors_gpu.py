@@ -71,7 +71,7 @@ def test_engine_capacity_errors_and_recovery(golden):
     assert torch.equal(h0, h1)                                         # same result after the failed calls
     with pytest.raises(Exception):
         LlamaEngine(wd, hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"],
-                    dtype=torch.float32, device=DEV, cache_cap=48, max_new=8, max_prefill_rows=32, img_ids=[], n_seq=5)
+                    dtype=torch.float32, device=DEV, cache_cap=48, max_new=8, max_prefill_rows=32, img_ids=[], n_seq=9)          # 1..8 slots
 
 
 def test_preprocess_and_misc_argument_errors():

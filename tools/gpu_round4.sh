@@ -5,6 +5,7 @@
 #   bench              `python bench.py` (N = 1, defaults) + the driver-like command -> gpurun_out/r4_bench*.json
 #   prof               rocprofv3 --kernel-trace --stats of the bench command (shipped schedule and --no-overlap) and the per-kernel
 #                      trace of one UNet forward                           -> gpurun_out/r4/..., summarised by summarize_round4.py
+#   pmc_gemv / prof_bench   the decode-GEMV traffic passes only / the two bench profiles only (no UNet trace)
 #   pmc                counter passes (each set in its own --pmc --kernel-trace run, never with sys/hip traces): the dominant MFMA
 #                      kernels on the SHIPPED tile table through gemm_ubench, attention through tools/attn_pmc.py, decode GEMV
 #                      FETCH_SIZE / WRITE_SIZE through bench.py --mllm-only -> gpurun_out/r4/..., summarised likewise
@@ -44,5 +45,19 @@ pmc)
   echo "$CASES" > gpurun_out/r4/cases.txt
   python tools/summarize_round4.py pmc
   find gpurun_out/r4 -name "*.csv" -size +8M -delete;;
+pmc_gemv)
+  # only the decode-GEMV traffic passes (the GEMM / attention counter sets above are tied to the tile table, which did not change)
+  rm -rf gpurun_out/r4/fetch gpurun_out/r4/write; mkdir -p gpurun_out/r4
+  B1="python bench.py --mllm-only --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-tolerance-modes"
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r4/fetch -o p -- $B1 > gpurun_out/r4_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r4/write -o p -- $B1 > gpurun_out/r4_write.log 2>&1
+  find gpurun_out/r4 -name "*.csv" -size +8M -delete; tail -1 gpurun_out/r4_fetch.log | cut -c1-200;;
+prof_bench)
+  rm -rf gpurun_out/r4/stats_overlap gpurun_out/r4/stats_serial; mkdir -p gpurun_out/r4
+  B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-tolerance-modes --no-roofline"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/stats_overlap -o b -- $B > gpurun_out/r4_overlap.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/stats_serial -o b -- $B --no-overlap > gpurun_out/r4_serial.log 2>&1
+  find gpurun_out/r4 -name "*kernel_trace.csv" -delete
+  python tools/summarize_round4.py stats | cut -c1-600;;
 *) echo "unknown stage $stage"; exit 2;;
 esac
