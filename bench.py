@@ -547,9 +547,10 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
             recs = [v for k, v in pmcj.get("gemv_hbm_traffic", {}).items() if k.split("<")[0] == base and v.get("dispatches")]
             if recs:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in recs) / sum(v["dispatches"] for v in recs))
-            us = [v for k, v in pmcj.get("gemv_avg_us_under_render", {}).items() if k.split("<")[0] == base]
+            calls = pmcj.get("gemv_calls_under_render", {})          # launch-weighted over the template instances when recorded
+            us = [(v, calls.get(k, 1)) for k, v in pmcj.get("gemv_avg_us_under_render", {}).items() if k.split("<")[0] == base]
             if us:
-                under_render_us = round(sum(us) / len(us), 3)
+                under_render_us = round(sum(v * c for v, c in us) / sum(c for _, c in us), 3)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel": "ss::" + kern, "slots_per_sweep": GRP,
@@ -698,17 +699,20 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         roof_mllm = roof
         from seedstory import tune as _tune
         ff1_cfg = _tune.lookup(Mg, Ng, Kg, 1)
-        # the counters describe ONE tile table: a record collected on another table (or carrying no table hash: rounds 1-3) is
-        # refused rather than quoted (the round-3 line carried the ff1 over-fetch of a retired XCD group)
+        # the counters describe ONE tile configuration: a record taken with another (cfg, XCD group) than the shipped table holds for
+        # this shape (or carrying neither: rounds 1-3) is refused rather than quoted (the round-3 line carried the
+        # ff1 over-fetch of a retired XCD group).  Checked per row, so that ADDING shapes to the table leaves the record valid.
         import hashlib
         table_sha = hashlib.sha256(open(os.path.join(ROOT, "seed-story_amd", "seedstory", "tune_gfx950.json"), "rb").read()).hexdigest()[:16]
         ghbm = pmcj.get("gemm_hbm_traffic", {})
         ff1_rec = ghbm.get("ff1_%dx%dx%d_geglu" % (Mg, Ng, Kg)) or ghbm.get("ff1_%dx%dx%d" % (Mg, Ng, Kg)) or {}
-        traffic_ok = bool(ff1_rec) and pmcj.get("tile_table_sha16") == table_sha      # (the record is keyed by the GEMM's shape)
+        shipped_cfg = "%d/%d" % tuple(ff1_cfg) if ff1_cfg else None
+        traffic_ok = bool(ff1_rec) and ff1_rec.get("cfg_swz") is not None and ff1_rec.get("cfg_swz") == shipped_cfg
         ff1_traffic = ff1_rec.get("hbm_bytes_per_launch") if traffic_ok else None
-        traffic_note = ("HBM-side bytes per launch of the ff1 GEMM from profiles/round4_pmc_summary.json (collected on tile table %s)" % table_sha
-                        if ff1_traffic else "no PMC record for the shipped tile table (sha16 %s; record: %s) — traffic withheld"
-                        % (table_sha, pmcj.get("tile_table_sha16")))
+        traffic_note = ("HBM-side bytes per launch of the ff1 GEMM from profiles/round4_pmc_summary.json, counters collected on tile cfg/XCD group "
+                        "%s = the shipped table's entry for this shape" % shipped_cfg
+                        if ff1_traffic else "no PMC record of this shape on the shipped tile (table: %s; record: %s) — traffic withheld"
+                        % (shipped_cfg, ff1_rec.get("cfg_swz")))
         roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": ff1_traffic,
                 "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
@@ -930,6 +934,8 @@ def main():
     runner.sts = None
     runner.warm(args.warmup)
     barrier()
+    from seedstory import tune as _tt0
+    tuned_before = len(_tt0.tuned_log())            # shapes the shipped table lacked, tuned before the clock starts
     t0 = time.perf_counter()
     runner.run(args.steps)
     barrier()
@@ -1017,6 +1023,8 @@ def main():
                "per_rank": per_rank,
                "tolerance_modes": tol_modes,
                "tile_table": {"entries": len(_tt.export_table()), "tuned_in_this_process": len(_tt.tuned_log()),
+                              "tuned_before_timed_region": tuned_before,
+                              "tuned_shapes": [[k, list(sh), c, x, round(us, 1)] for k, sh, c, x, us in _tt.tuned_log()],
                               "note": "GEMM/conv tile choices come from seedstory/tune_gfx950.json; shapes missing from it are "
                                       "tuned explicitly (ss_gemm_tune) BEFORE the timed region"},
                "roofline": roof, "cpu_baseline": cpu}
