@@ -170,18 +170,52 @@ def _llama7b_weights():
 
         def rnd(*s):
             return torch.randn(*s, generator=g) * 0.02
-        w = {"model.embed_tokens.weight": rnd(VOCAB, H), "lm_head.weight": rnd(VOCAB, H), "model.norm.weight": 1.0 + 0.1 * torch.randn(H, generator=g)}
+        bf, f32 = {}, {}
+
+        def put(name, t):        # the raw draw is dropped right away: peak host memory = fp32 + bf16 copies + one tensor
+            bf[name] = t.to(torch.bfloat16)
+            f32[name] = bf[name].float()
+        put("model.embed_tokens.weight", rnd(VOCAB, H))
+        put("lm_head.weight", rnd(VOCAB, H))
+        put("model.norm.weight", 1.0 + 0.1 * torch.randn(H, generator=g))
         for l in range(32):
             p_ = "model.layers.%d." % l
             for n, (o, i) in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)), ("self_attn.o_proj", (H, H)),
                               ("mlp.gate_proj", (INTER, H)), ("mlp.up_proj", (INTER, H)), ("mlp.down_proj", (H, INTER))):
-                w[p_ + n + ".weight"] = rnd(o, i)
-            w[p_ + "input_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
-            w[p_ + "post_attention_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
-        _W7B["bf"] = {k: v.to(torch.bfloat16) for k, v in w.items()}
-        _W7B["f32"] = {k: v.float() for k, v in _W7B["bf"].items()}
+                put(p_ + n + ".weight", rnd(o, i))
+            put(p_ + "input_layernorm.weight", 1.0 + 0.1 * torch.randn(H, generator=g))
+            put(p_ + "post_attention_layernorm.weight", 1.0 + 0.1 * torch.randn(H, generator=g))
+        _W7B["bf"], _W7B["f32"] = bf, f32
         _W7B["t"] = time.time() - t0
     return _W7B["f32"], _W7B["bf"], _W7B["t"]
+
+
+_L7_KEYS = ("prefill_hidden", "prefill_logits", "cont_hidden", "cont_logits", "decode_hidden")
+
+
+def _llama7b_case():
+    return (synth.randint(741, (64,), 3, 32000), synth.randint(742, (66,), 3, 32000), synth.randint(743, (4,), 3, 32000).tolist())
+
+
+def llama7b_truth():
+    """Oracle outputs of `test_llama_7b_all_32_layers` (fp32 and bf16 runs of O.llama_forward over the whole 32-layer model on the
+    host: ~30 s on the GPU box's 128 threads), cached in tests/golden/llama7b_truth.safetensors keyed on the weights and ids
+    (truth_cache.py).  No GPU needed: oracle/make_golden_mllm_full.py calls this to write the file."""
+    import truth_cache as TC
+    w32, wbf, _ = _llama7b_weights()
+    prompt, cont, forced = _llama7b_case()
+    dims = O.LlamaDims(H, NH, 32, INTER, VOCAB)
+
+    def compute():
+        out = {}
+        with torch.no_grad():
+            for tag, wd in (("f32", w32), ("bf16", wbf)):
+                r = _oracle_run(wd, dims, wd["model.embed_tokens.weight"], prompt, cont, forced)
+                out.update({"%s.%s" % (tag, k): r[k] for k in _L7_KEYS})
+        return out
+    R, how = TC.load_or_compute("llama7b_truth", TC.tensors_key(wbf, prompt, cont, forced), compute,
+                                note="LLaMA-2-7B 32 layers: prefill 64 + 66-row continuation + 3 decode tokens, fp32 and bf16 oracle runs")
+    return ({k: R["f32." + k] for k in _L7_KEYS}, {k: R["bf16." + k] for k in _L7_KEYS}, how)
 
 
 def test_llama_7b_all_32_layers():
@@ -195,13 +229,9 @@ def test_llama_7b_all_32_layers():
     NL32 = 32
     w32, wbf, t_w = _llama7b_weights()
     dims = O.LlamaDims(H, NH, NL32, INTER, VOCAB)
-    prompt = synth.randint(741, (64,), 3, 32000)
-    cont = synth.randint(742, (66,), 3, 32000)
-    forced = synth.randint(743, (4,), 3, 32000).tolist()
+    prompt, cont, forced = _llama7b_case()
     t0 = time.time()
-    with torch.no_grad():
-        r32 = _oracle_run(w32, dims, w32["model.embed_tokens.weight"], prompt, cont, forced)
-        rbf = _oracle_run(wbf, dims, wbf["model.embed_tokens.weight"], prompt, cont, forced)
+    r32, rbf, how = llama7b_truth()
     t_o = time.time() - t0
     res = {}
     for dtype, wd in ((torch.float32, w32), (torch.bfloat16, wbf)):
@@ -218,7 +248,7 @@ def test_llama_7b_all_32_layers():
                       "decode_hidden": eng.hidden_rows[:3].float().cpu(), "k31": eng.k_cache[31, :, :eng.lengths()[0]].float().cpu()}
         del eng
         torch.cuda.empty_cache()
-    print("LLaMA-2-7B, all 32 layers (weights %.0f s, host oracle fp32 + bf16 %.0f s):" % (t_w, t_o))
+    print("LLaMA-2-7B, all 32 layers (weights %.0f s, host oracle fp32 + bf16 %s in %.0f s):" % (t_w, how, t_o))
     for key in ("prefill_hidden", "prefill_logits", "cont_hidden", "cont_logits", "decode_hidden"):
         e32 = rel(res[torch.float32][key], r32[key])
         ebf, e_bf32, theirs = rel(res[torch.bfloat16][key], rbf[key]), rel(res[torch.bfloat16][key], r32[key]), rel(rbf[key], r32[key])
@@ -229,22 +259,47 @@ def test_llama_7b_all_32_layers():
         assert ebf <= 2.5 * theirs + 2e-3, (key, ebf, theirs)
 
 
-def test_vit_g_all_48_blocks():
-    """The WHOLE Qwen ViT-G (448^2, patch 14, width 1664, 48 blocks x 16 heads, MLP 8192, attn_pool to 256 x 4096: 1.9 B
-    parameters) on one image, fp32 and bf16, against the oracle on the host (4.1 TFLOP: ~10 s).  The 1-block test above is
-    pinned on the real reference class; this one covers the depth."""
-    import time
-    from src.models.qwen_visual import VisionTransformerWithAttnPool
-    c = dict(width=1664, layers=48, heads=16, mlp_width=8192, patch=14, out_dim=4096, n_queries=256, image=448)
-    t0 = time.time()
+_VITG = dict(width=1664, layers=48, heads=16, mlp_width=8192, patch=14, out_dim=4096, n_queries=256, image=448)
+_TRUTH_ROW_STRIDE = 8            # the cached truths of [*, 256, 4096] outputs keep every 8th row; the tests compare those rows
+
+
+def _vitg_weights():
+    c = _VITG
     wd = synth.vit_weights(33, c["width"], c["layers"], c["heads"], c["mlp_width"], c["patch"], c["out_dim"], c["n_queries"])
     wbf = {k: v.to(torch.bfloat16) for k, v in wd.items()}
-    w32 = {k: v.float() for k, v in wbf.items()}
-    x = synth.normal_like(133, (1, 3, c["image"], c["image"]), 1.0).to(torch.bfloat16)
+    return wbf, synth.normal_like(133, (1, 3, c["image"], c["image"]), 1.0).to(torch.bfloat16)
+
+
+def vitg48_truth(wbf=None, x=None):
+    """Oracle outputs of `test_vit_g_all_48_blocks` (O.vit_forward in fp32 and bf16 on the host), every 8th of the 256 output
+    rows, cached in tests/golden/vitg48_truth.safetensors (truth_cache.py)."""
+    import truth_cache as TC
+    c = _VITG
+    if wbf is None:
+        wbf, x = _vitg_weights()
     kw = dict(width=c["width"], layers=c["layers"], heads=c["heads"], patch=c["patch"], out_dim=c["out_dim"], n_queries=c["n_queries"])
-    with torch.no_grad():
-        r32 = O.vit_forward(w32, x.float(), **kw)
-        rbf = O.vit_forward(wbf, x, **kw)
+
+    def compute():
+        with torch.no_grad():
+            r32 = O.vit_forward({k: v.float() for k, v in wbf.items()}, x.float(), **kw)
+            rbf = O.vit_forward(wbf, x, **kw)
+        return {"f32": r32[0, ::_TRUTH_ROW_STRIDE].float(), "bf16": rbf[0, ::_TRUTH_ROW_STRIDE]}
+    R, how = TC.load_or_compute("vitg48_truth", TC.tensors_key(wbf, x, _TRUTH_ROW_STRIDE), compute,
+                                note="Qwen ViT-G 48 blocks + attn_pool on one 448^2 image: rows [::8] of the [256, 4096] output")
+    return R["f32"], R["bf16"], how
+
+
+def test_vit_g_all_48_blocks():
+    """The WHOLE Qwen ViT-G (448^2, patch 14, width 1664, 48 blocks x 16 heads, MLP 8192, attn_pool to 256 x 4096: 1.9 B
+    parameters) on one image, fp32 and bf16, against the oracle on the host (4.1 TFLOP: ~10 s; cached, see `vitg48_truth`).
+    The 1-block test above is pinned on the real reference class; this one covers the depth."""
+    import time
+    from src.models.qwen_visual import VisionTransformerWithAttnPool
+    c = _VITG
+    t0 = time.time()
+    wbf, x = _vitg_weights()
+    w32 = {k: v.float() for k, v in wbf.items()}
+    r32, rbf, how = vitg48_truth(wbf, x)
     t_o = time.time() - t0
     out = {}
     for dtype, w in ((torch.float32, w32), (torch.bfloat16, wbf)):
@@ -253,61 +308,69 @@ def test_vit_g_all_48_blocks():
         missing, unexpected = m.load_state_dict(w, strict=False)
         assert not missing and not unexpected
         m = m.to(DEV, dtype)
-        out[dtype] = m(x.to(DEV, dtype)).float().cpu()
+        y = m(x.to(DEV, dtype)).float().cpu()
+        assert y.shape == (1, 256, 4096)
+        out[dtype] = y[0, ::_TRUTH_ROW_STRIDE]
         del m
         torch.cuda.empty_cache()
     e32 = rel(out[torch.float32], r32)
     ebf, e_bf32, theirs = rel(out[torch.bfloat16], rbf), rel(out[torch.bfloat16], r32), rel(rbf, r32)
-    print("ViT-G, all 48 blocks + attn_pool (weights + host oracle %.0f s): fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, "
-          "HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e" % (t_o, e32, ebf, e_bf32, theirs))
-    assert out[torch.float32].shape == (1, 256, 4096) and e32 < 1e-4
+    print("ViT-G, all 48 blocks + attn_pool (weights + host oracle %s in %.0f s): fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, "
+          "HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e" % (how, t_o, e32, ebf, e_bf32, theirs))
+    assert e32 < 1e-4
     assert e_bf32 <= 1.5 * theirs + 2e-3 and ebf <= 2.5 * theirs + 2e-3
 
 
-def test_story_three_steps_full_size_mllm_half():
-    """BASELINE configs[1] at REAL size, end to end through the reference API surface: whole ViT-G (48 blocks) on the start
-    image -> 3 story steps of ``ContinuousLVLM.generate`` on the whole LLaMA-2-7B (32 layers) with the full-size input /
-    output resamplers, the context growing by caption + image tokens and the regressed feature each step
-    (gen_george.py:168-243 on token ids).  Captions are teacher-forced (random weights never open an image), so the oracle
-    evaluates each step as ONE causal pass over prompt + forced tokens — the same function as the token-by-token loop.
-    Compared: ``img_gen_feat`` [1, 256, 4096] of every step, fp32 and bf16 (gated by the oracle's own bf16 distance)."""
-    import time
-    from src.models.qwen_visual import Resampler, VisionTransformerWithAttnPool
-    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
-    from src.models_clm.models import ContinuousLVLM
-    w32, wbf, _ = _llama7b_weights()
-    vc = dict(width=1664, layers=48, heads=16, mlp_width=8192, patch=14, out_dim=4096, n_queries=256)
+_STORY_CAP, _STORY_STEPS = 8, 3
+
+
+def _story_setup():
+    """Seeded weights and ids of the 3-step story (shared by the oracle side and the HIP side)."""
+    vc = _VITG
     vit_bf = {k: v.to(torch.bfloat16) for k, v in synth.vit_weights(33, vc["width"], vc["layers"], vc["heads"], vc["mlp_width"], vc["patch"],
                                                                       vc["out_dim"], vc["n_queries"]).items()}
     rin_bf = {k: v.to(torch.bfloat16) for k, v in synth.resampler_weights(21, "", 8, H).items()}
     rout_bf = {k: v.to(torch.bfloat16) for k, v in synth.resampler_weights(22, "", 16, H).items()}
     img = synth.normal_like(134, (1, 3, 448, 448), 1.0).to(torch.bfloat16)
-    CAP, STEPS = 8, 3
-    caps = [synth.randint(750 + i, (CAP,), 3, 32000).tolist() for i in range(STEPS + 1)]
-    boi, eoi = IMG_IDS[0], IMG_IDS[-1]
+    caps = [synth.randint(750 + i, (_STORY_CAP,), 3, 32000).tolist() for i in range(_STORY_STEPS + 1)]
+    return dict(vit_bf=vit_bf, rin_bf=rin_bf, rout_bf=rout_bf, img=img, caps=caps)
+
+
+def _story_context(ids):
+    boi = IMG_IDS[0]
+    pos = [i + 1 for i, t in enumerate(ids) if t == boi]
+    mask = torch.zeros(1, len(ids), dtype=torch.bool)
+    for p_ in pos:
+        mask[0, p_:p_ + 64] = True
+    return mask
+
+
+def story3_truth(st=None):
+    """Oracle side of `test_story_three_steps_full_size_mllm_half`: `img_gen_feat` of the three story steps in fp32 and bf16
+    (whole ViT-G, whole LLaMA-2-7B, full-size resamplers on the host: ~70 s on the GPU box), every 8th of the 256 rows, cached in
+    tests/golden/story3_truth.safetensors (truth_cache.py).  Captions are teacher-forced, so each step is ONE causal pass over
+    prompt + forced tokens — the same function as the token-by-token loop."""
+    import truth_cache as TC
+    st = st or _story_setup()
+    w32, wbf, _ = _llama7b_weights()
+    vc = _VITG
+    CAP, STEPS, caps = _STORY_CAP, _STORY_STEPS, st["caps"]
     dims = O.LlamaDims(H, NH, 32, INTER, VOCAB)
     vkw = dict(width=vc["width"], layers=vc["layers"], heads=vc["heads"], patch=vc["patch"], out_dim=vc["out_dim"], n_queries=vc["n_queries"])
 
     def to(d, dtype):
         return {k: v.to(dtype) for k, v in d.items()}
 
-    def context(ids):
-        pos = [i + 1 for i, t in enumerate(ids) if t == boi]
-        mask = torch.zeros(1, len(ids), dtype=torch.bool)
-        for p_ in pos:
-            mask[0, p_:p_ + 64] = True
-        return mask
-
     def oracle_story(dtype):
         wl = w32 if dtype == torch.float32 else wbf
-        wv, wi, wo = to(vit_bf, dtype), to(rin_bf, dtype), to(rout_bf, dtype)
+        wv, wi, wo = to(st["vit_bf"], dtype), to(st["rin_bf"], dtype), to(st["rout_bf"], dtype)
         feats = []
         with torch.no_grad():
-            embeds = O.vit_forward(wv, img.to(dtype), **vkw)                                   # [1, 256, 4096]
+            embeds = O.vit_forward(wv, st["img"].to(dtype), **vkw)                              # [1, 256, 4096]
             ids = [1] + caps[0] + IMG_IDS
-            for st in range(STEPS):
-                forced = caps[st + 1] + IMG_IDS + [2]
-                mask = context(ids)
+            for step in range(STEPS):
+                forced = caps[step + 1] + IMG_IDS + [2]
+                mask = _story_context(ids)
                 x = wl["model.embed_tokens.weight"][torch.tensor([ids + forced[:-1]])].clone()
                 lm = O.resampler_forward(wi, "", embeds, 32)
                 x[0, :len(ids)][mask[0]] = lm.reshape(-1, H)
@@ -316,10 +379,41 @@ def test_story_three_steps_full_size_mllm_half():
                 rows = hid[0, S - 1:]                      # row j = state whose input was generated id j - 1 ... (models.py:182-184)
                 e = CAP + 65                               # index of </img> in the generated ids
                 feat = O.resampler_forward(wo, "", rows[e - 64 + 1:e + 1][None], 32)   # inputs <img_00000> .. <img_00063>
-                feats.append(feat.float())
+                feats.append(feat)
                 ids = ids + forced[:CAP] + IMG_IDS
                 embeds = torch.cat([embeds, feat], dim=0)
         return feats
+
+    def compute():
+        out = {}
+        for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            for i, f in enumerate(oracle_story(dtype)):
+                out["%s.step%d" % (tag, i)] = f[0, ::_TRUTH_ROW_STRIDE].clone()
+        return out
+    key = TC.tensors_key(wbf, st["vit_bf"], st["rin_bf"], st["rout_bf"], st["img"], [t for c in caps for t in c], _TRUTH_ROW_STRIDE)
+    R, how = TC.load_or_compute("story3_truth", key, compute,
+                                note="3-step story, MLLM half at real size: img_gen_feat rows [::8] of every step, fp32 and bf16 oracle runs")
+    return ([R["f32.step%d" % i] for i in range(STEPS)], [R["bf16.step%d" % i] for i in range(STEPS)], how)
+
+
+def test_story_three_steps_full_size_mllm_half():
+    """BASELINE configs[1] at REAL size, end to end through the reference API surface: whole ViT-G (48 blocks) on the start
+    image -> 3 story steps of ``ContinuousLVLM.generate`` on the whole LLaMA-2-7B (32 layers) with the full-size input /
+    output resamplers, the context growing by caption + image tokens and the regressed feature each step
+    (gen_george.py:168-243 on token ids).  Captions are teacher-forced (random weights never open an image), so the oracle
+    (`story3_truth`, cached) evaluates each step as ONE causal pass over prompt + forced tokens — the same function as the
+    token-by-token loop.  Compared: ``img_gen_feat`` [1, 256, 4096] of every step (every 8th row), fp32 and bf16 (gated by the
+    oracle's own bf16 distance)."""
+    import time
+    from src.models.qwen_visual import Resampler, VisionTransformerWithAttnPool
+    from src.models_clm.modeling_llama_xformer import LlamaConfig, LlamaForCausalLM
+    from src.models_clm.models import ContinuousLVLM
+    w32, wbf, _ = _llama7b_weights()
+    vc = _VITG
+    st = _story_setup()
+    vit_bf, rin_bf, rout_bf, img, caps = st["vit_bf"], st["rin_bf"], st["rout_bf"], st["img"], st["caps"]
+    CAP, STEPS = _STORY_CAP, _STORY_STEPS
+    context = _story_context
 
     def hip_story(dtype):
         cfg = LlamaConfig(hidden_size=H, intermediate_size=INTER, num_hidden_layers=32, num_attention_heads=NH, vocab_size=VOCAB)
@@ -340,13 +434,14 @@ def test_story_three_steps_full_size_mllm_half():
         feats = []
         embeds = vit(img.to(DEV, dtype))
         ids = [1] + caps[0] + IMG_IDS
-        for st in range(STEPS):
-            forced = caps[st + 1] + IMG_IDS + [2]
+        for step in range(STEPS):
+            forced = caps[step + 1] + IMG_IDS + [2]
             out = agent.generate(tokenizer=_Tok(IMG_IDS), input_ids=torch.tensor([ids]), image_embeds=embeds,
                                  embeds_cmp_mask=torch.ones(embeds.shape[0], dtype=torch.bool), ids_cmp_mask=context(ids),
                                  max_new_tokens=120, num_img_gen_tokens=64, forced_tokens=forced)
             assert out["generate_ids"].tolist() == forced and out["has_img_output"]
-            feats.append(out["img_gen_feat"].float().cpu())
+            assert out["img_gen_feat"].shape == (1, 256, H)
+            feats.append(out["img_gen_feat"].float().cpu()[0, ::_TRUTH_ROW_STRIDE])
             ids = ids + forced[:CAP] + IMG_IDS
             embeds = torch.cat([embeds, out["img_gen_feat"]], dim=0)                           # gen_george.py:224
         del agent, vit, llm
@@ -354,16 +449,17 @@ def test_story_three_steps_full_size_mllm_half():
         return feats
 
     t0 = time.time()
-    o32, obf = oracle_story(torch.float32), oracle_story(torch.bfloat16)
+    o32, obf, how = story3_truth(st)
     t_o = time.time() - t0
     h32, hbf = hip_story(torch.float32), hip_story(torch.bfloat16)
-    print("3-step story, MLLM half at real size (ViT-G 48 blocks, LLaMA-2-7B 32 layers, resamplers 4096 / 32 heads; host oracle %.0f s):" % t_o)
-    for st in range(STEPS):
-        e32 = rel(h32[st], o32[st])
-        ebf, e_bf32, theirs = rel(hbf[st], obf[st]), rel(hbf[st], o32[st]), rel(obf[st], o32[st])
+    print("3-step story, MLLM half at real size (ViT-G 48 blocks, LLaMA-2-7B 32 layers, resamplers 4096 / 32 heads; host oracle %s in %.0f s):"
+          % (how, t_o))
+    for step in range(STEPS):
+        e32 = rel(h32[step], o32[step])
+        ebf, e_bf32, theirs = rel(hbf[step], obf[step]), rel(hbf[step], o32[step]), rel(obf[step], o32[step])
         print("  step %d img_gen_feat: fp32 HIP vs oracle %.2e | bf16: HIP vs oracle-bf16 %.3e, HIP vs oracle-fp32 %.3e, oracle bf16 vs fp32 %.3e"
-              % (st + 1, e32, ebf, e_bf32, theirs))
-        assert h32[st].shape == (1, 256, H) and e32 < 1e-3            # the north-star gate, at real size, end to end
+              % (step + 1, e32, ebf, e_bf32, theirs))
+        assert e32 < 1e-3            # the north-star gate, at real size, end to end
         assert e_bf32 <= 1.5 * theirs + 2e-3 and ebf <= 2.5 * theirs + 2e-3
 
 

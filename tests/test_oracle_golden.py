@@ -1,5 +1,7 @@
 """CPU: the oracle restatement (oracle/seedstory_oracle.py) against the golden vectors that
 oracle/make_golden.py produced by running the REAL reference modules."""
+import os
+
 import torch
 
 import seedstory_oracle as O
@@ -252,3 +254,54 @@ def test_full_dimension_generate_fp32():
     e = max(i for i, t in enumerate(ids) if t == img_ids[-1])
     assert rel(_rows(out["hidden"][e - 64:e], gen["hidden_stride"]), g["gen_f32.feed.rows"]) < 2e-6
     assert rel(_rows(out["img_gen_feat"], gen["feat_stride"]), g["gen_f32.img_gen_feat.rows"]) < 2e-6
+
+
+def test_truth_cache_roundtrip_and_key_mismatch(tmp_path, monkeypatch):
+    """tests/truth_cache.py (the cache of full-size CPU-oracle truths used by the GPU tests): a file written under
+    SS_WRITE_GOLDEN_DIR loads back bit for bit when the key matches, and is ignored (recomputed) when any input tensor differs."""
+    import truth_cache as TC
+    g = torch.Generator().manual_seed(5)
+    w = {"a": torch.randn(300, 70, generator=g).to(torch.bfloat16), "b": torch.randn(9, generator=g)}
+    ids = [3, 1, 4, 1, 5]
+    key = TC.tensors_key(w, ids, 8)
+    assert key == TC.tensors_key(dict(reversed(list(w.items()))), ids, 8)        # dict order does not matter
+    w2 = {k: v.clone() for k, v in w.items()}
+    w2["a"][0, 0] += 1
+    assert TC.tensors_key(w2, ids, 8) != key and TC.tensors_key(w, ids + [9], 8) != key and TC.tensors_key(w, ids, 4) != key
+    calls = []
+
+    def compute():
+        calls.append(1)
+        return {"f32.x": torch.arange(12.0).reshape(3, 4), "bf16.x": torch.arange(12.0).reshape(3, 4).to(torch.bfloat16)}
+    monkeypatch.setattr(TC, "GOLDEN", str(tmp_path))
+    monkeypatch.setenv("SS_WRITE_GOLDEN_DIR", str(tmp_path))
+    monkeypatch.delenv("SS_IGNORE_TRUTH_CACHE", raising=False)
+    R, how = TC.load_or_compute("unit_truth", key, compute)
+    assert how == "computed" and len(calls) == 1
+    R2, how2 = TC.load_or_compute("unit_truth", key, compute)
+    assert how2 == "loaded" and len(calls) == 1
+    assert all(torch.equal(R[k], R2[k]) and R[k].dtype == R2[k].dtype for k in R)
+    R3, how3 = TC.load_or_compute("unit_truth", TC.tensors_key(w2, ids, 8), compute)
+    assert how3 == "computed" and len(calls) == 2
+
+
+def test_cached_full_size_truth_files_are_well_formed():
+    """The committed truth files of the full-size MLLM-half tests carry a key and the tensors the tests read (shapes, dtypes, finite values).
+    (Whether a box LOADS them is decided by the key over the weights it draws: oracle/synth.py is platform-independent by construction,
+    the torch CPU generator of the 7B weights was checked to draw the same stream on the GPU box's host, tools/randn_fingerprint.py.)"""
+    from safetensors import safe_open
+    import truth_cache as TC
+    want = {"vitg48_truth": {"f32": (32, 4096), "bf16": (32, 4096)},
+            "llama7b_truth": {"f32.prefill_hidden": (64, 4096), "bf16.cont_hidden": (66, 4096), "f32.decode_hidden": (3, 4096),
+                              "f32.prefill_logits": (32066,), "bf16.cont_logits": (32066,)},
+            "story3_truth": {"f32.step0": (32, 4096), "bf16.step2": (32, 4096)}}
+    for name, tensors in want.items():
+        path = os.path.join(TC.GOLDEN, name + ".safetensors")
+        assert os.path.exists(path), path
+        with safe_open(path, "pt") as f:
+            meta = f.metadata() or {}
+            assert len(meta.get("key", "")) == 64 and "make_golden_mllm_full" in meta.get("generator", "")
+            for k, shape in tensors.items():
+                t = f.get_tensor(k)
+                assert tuple(t.shape) == shape and bool(torch.isfinite(t.float()).all()), (name, k, t.shape)
+                assert t.dtype == (torch.bfloat16 if k.startswith("bf16") else torch.float32), (name, k, t.dtype)
