@@ -234,6 +234,7 @@ class StoryRingBackend(SlotRingBackend):
         self.sts = None
         self.render_stream = torch.cuda.Stream(device=device) if adapter is not None else None
         self.lock = threading.Lock()
+        self._ready = {}            # round -> event recorded behind the round's MLLM half (the render stream waits on it)
 
     def _stories(self):
         bm = self.bm
@@ -269,6 +270,12 @@ class StoryRingBackend(SlotRingBackend):
             self.eng.select(b)
             tensors += [self.eng.k_cache[:, :, lo:hi], self.eng.v_cache[:, :, lo:hi]]      # views: packed without a staging copy
             meta += [lo, hi]
+        if self.render_stream is not None:
+            # the render of this round runs on ANOTHER stream (and thread): it must not read the regressed features before the
+            # MLLM half that produces them has run (under RCCL nothing between here and the render synchronises the host)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ready[r] = ev
         return meta, tensors
 
     def alloc(self, meta):
@@ -307,7 +314,10 @@ class StoryRingBackend(SlotRingBackend):
             return
         feat = tensors[1][:, -1]                                              # [S, 256, 4096]: this round's regressed feature
         torch.cuda.set_device(self.device)
+        ev = self._ready.pop(r, None)
         with self.lock, torch.cuda.stream(self.render_stream):
+            if ev is not None:
+                self.render_stream.wait_event(ev)
             self.adapter.generate(image_embeds=feat.contiguous(), num_inference_steps=self.steps, output_type="pt")
         self.render_stream.synchronize()
 
