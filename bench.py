@@ -718,6 +718,11 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
                 "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
                 "traffic_note": traffic_note, "tile_table_sha16": table_sha,
                 "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
+                "sustained_ceiling": {"value": 1300.0, "unit": "TFLOP/s", "frac_of_ceiling": round(flops / (ms * 1e-3) / 1.3e15, 4),
+                                      "note": "what this part sustains on RANDOM bf16 operands (power-limited clock: 8192^3 GEMM at MFMA busy "
+                                              "0.68-0.80 and 1.90-1.62 GHz effective = 1.30-1.31 PFLOP/s with either kernel family, "
+                                              "profiles/round4_pmc_summary.json gemm_8192cubed_*; MI355X_MICROARCH.md DVFS note: 1,247 TFLOP/s "
+                                              "random vs 1,483 zero-filled for the same binary); `frac` above stays against the nominal 2.5 PFLOP/s"},
                 "dominant_kernel": {"kernel": "ss::gemm_sp_kernel (tile table cfg %s) + GEGLU epilogue" % (ff1_cfg,),
                                     "shape_MNK": [Mg, Ng, Kg], "avg_launch_us": round(gemm_us, 1),
                                     "achieved": round(gemm_tf, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / 2500.0, 4),
