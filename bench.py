@@ -828,11 +828,12 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the MLLM half and the render of a round back to back (default: the next round's MLLM half "
                          "runs on a second HIP stream under the current round's render)")
-    ap.add_argument("--stories-per-gpu", type=int, default=None, choices=[1, 2, 3, 4, 6, 8],
+    ap.add_argument("--stories-per-gpu", type=int, default=None, choices=[1, 2, 3, 4, 6, 8, 12, 16],
                     help="stories resident per GPU, advanced in lock-step (1 = the reference's batch-1 loop); more than 4 "
                          "run as groups of <= 4 decode slots over shared weights and ONE render batch (UNet batch 2 x stories).  "
                          "Default: 8 for the replica partition (round 4, same box: 1.995 / 1.996 story-steps/s against 1.927 / 1.935 "
-                         "with 4 — the batch-16 UNet forward costs 59.0 ms per 8 samples against 61.1), 4 for the slot ring")
+                         "with 4 — the batch-16 UNet forward costs 59.0 ms per 8 samples against 61.1), 4 for the slot ring; 12 / 16 = two decode "
+                         "groups and a UNet batch of 24 / 32 (not measured yet: their shapes are tuned in-process)")
     ap.add_argument("--max-slots", type=int, default=0,
                     help="sequence slots per decode engine (stories sharing one sweep of the weights per token): 1..8; "
                          "default 8 (3 - 8 slots decode through the MFMA form of the GEMV)")
