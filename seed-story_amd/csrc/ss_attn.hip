@@ -715,6 +715,327 @@ void flash_attn3_kernel(const AttnArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// (1d) flash attention v3p — OPTION (tuning knob attn_ver = 5: PIPE, 6: addresses only; head_dim <= 64), not the shipped default.
+//   Same data path, softmax and fragment layouts as v3 with the two changes the instruction budget of v3 asks for
+//   (per 64-key tile and wave 1152 matrix-pipe cycles against ~1190 VALU cycles, MFMA busy 0.34-0.41):
+//   * S(t+1) = K(t+1) Q^T is ISSUED before the softmax of tile t: the 16 S MFMAs of the next tile run on the matrix pipe
+//     while this wave's VALU works through the 32 exp2 / max3 / packs of the current one (two named score sets, the loop
+//     is unrolled by two so that neither set is indexed at run time).  K(t+1) therefore has to have landed one tile
+//     earlier than in v3: the wave drains its DMA counter at the top of every iteration (the tile it waits for was
+//     issued one full iteration before);
+//   * the DMA source addresses are (per-lane base, loop-invariant) + (wave-uniform tile advance): v3 recomputes the 64-bit
+//     byte offset of every key row per tile with quarter-rate integer multiplies (~270 VALU cycles per tile).
+//   Bit-for-bit the same arithmetic per score as v3 (same MFMA order inside S, softmax and PV), so results are equal.
+//   PIPE = false keeps v3's loop (S(t) inside iteration t, tile t+1 still in flight at the barrier, 3 waves per SIMD) and
+//   takes only the address change — the two effects can be measured apart; PIPE = true needs 204 VGPRs (2 waves per SIMD).
+// --------------------------------------------------------------------------------------------
+template <typename T, int HD, bool PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 3)))
+void flash_attn3p_kernel(const AttnArgs a) {
+    static_assert(HD == 64, "v3p: head_dim <= 64");
+    constexpr int V = 8;
+    constexpr int BQ2 = 128;             // query rows per block: 4 waves x 32
+    constexpr int CPR = HD / V;          // 16-byte chunks per key row
+    constexpr int KPI = 64 / CPR;        // keys per DMA instruction
+    constexpr int NI = kBKV / KPI;       // DMA instructions per tile per operand
+    constexpr int IPW = NI / 4;          // ... per wave
+    constexpr int ROWB = HD * 2;         // bytes per key row
+    constexpr int TILE_B = kBKV * ROWB;  // bytes of one K (or V) tile
+    constexpr int NDB = HD / 16, NKB = kBKV / 16, NKS = HD / 32;
+    constexpr int NSTAGE = 3;
+    constexpr float THR_L2 = 8.0f;       // deferred-rescale threshold, log2 units
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    int bh, qblk;
+    if (gridDim.y == 1 && a.xcd_heads > 0) {      // XCD-aware 1-D grid, as v3
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int nqb = a.xcd_heads;
+        bh = (j / nqb) * 8 + xcd;
+        qblk = j - (j / nqb) * nqb;
+    } else {
+        bh = blockIdx.y; qblk = blockIdx.x;
+    }
+    const int b = bh / a.n_heads, h = bh % a.n_heads;
+    const int kvl = a.ragged ? a.kv_len_b[b] : a.kv_len;
+    const int q0 = qblk * BQ2;
+    const int hd = a.hd;
+    const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+    const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int shift = kvl - a.q_len;
+    const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_void2_t*)smem_raw);
+    const float sl2 = a.scale * 1.4426950408889634f;   // scores kept in the log2 domain
+    const float thr_raw = THR_L2 / fmaxf(sl2, 1e-30f);
+
+    int qi[2];
+    uint4 qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = q0 + wid * 32 + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + grp * 8;
+            qf[qb][ks] = (qi[qb] < a.q_len && d < hd) ? ld16(qp + (int64_t)qi[qb] * a.q_ss + d) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    f32x4_t o[2][NDB], osum[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        osum[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) o[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    float m_run[2] = {-1e30f, -1e30f};
+    const uint4 ones = make_uint4(OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair);
+
+    int kv_end = kvl;
+    if (a.causal_br) {
+        const int lim = q0 + BQ2 - 1 + shift + 1;
+        if (lim < kv_end) kv_end = lim;
+        if (kv_end < 0) kv_end = 0;
+    }
+    const int ntiles = (kv_end + kBKV - 1) / kBKV;
+    if (ntiles == 0) {                   // (causal blocks with no visible key: v3 stores zeros through its epilogue, so do we)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (qi[qb] >= a.q_len) continue;
+            T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi[qb] * a.o_ss;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = db * 16 + grp * 4 + r;
+                    if (d < hd) Tr<T>::st(op + d, 0.f);
+                }
+        }
+        return;
+    }
+
+    auto vsw = [](int r) { return (r >> 1) & 3; };       // V image: 32-byte chunk c of key row r at chunk c ^ vsw(r)
+
+    // ---- DMA coordinates: everything that depends on the lane is loop-invariant -----------------------------------
+    const int skey = lane / CPR, spc = lane % CPR;
+    int dkey[IPW];
+    const T* kbase_l[IPW];
+    const T* vbase_l[IPW];
+    bool kin[IPW], vin[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int key = (wid * IPW + i) * KPI + skey;           // key row inside a tile
+        const int lc = spc ^ (key & (CPR - 1));                 // K: 16-byte chunks swizzled on the source side
+        const int lv = ((((spc >> 1) ^ vsw(key)) << 1) | (spc & 1));   // V: 32-byte chunks
+        dkey[i] = key;
+        kin[i] = lc * V < hd;
+        vin[i] = lv * V < hd;
+        kbase_l[i] = kp + (int64_t)key * a.k_ss + lc * V;
+        vbase_l[i] = vp + (int64_t)key * a.v_ss + lv * V;
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const uint32_t kbase = lds0 + (uint32_t)(buf * 2 * TILE_B);
+        const uint32_t vbase = kbase + TILE_B;
+        const int64_t kadv = (int64_t)t * kBKV * a.k_ss;        // wave-uniform
+        const int64_t vadv = (int64_t)t * kBKV * a.v_ss;
+        const int t0k = t * kBKV;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const bool inr = t0k + dkey[i] < kvl;
+            const T* ks = (inr && kin[i]) ? kbase_l[i] + kadv : zero;
+            const T* vs = (inr && vin[i]) ? vbase_l[i] + vadv : zero;
+            const uint32_t roff = (uint32_t)((wid * IPW + i) * KPI * ROWB);
+            attn_dma16(ks, __builtin_amdgcn_readfirstlane(kbase + roff));
+            attn_dma16(vs, __builtin_amdgcn_readfirstlane(vbase + roff));
+        }
+    };
+
+    const int vrow = grp * 4 + (l15 >> 2);
+    uint32_t voff[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) voff[db] = (uint32_t)(vrow * ROWB + ((db ^ vsw(vrow)) << 5) + (l15 & 3) * 8);
+
+    // S^T = K Q^T of the tile in ring slot `slot`, both 16-row query blocks
+    auto compute_s = [&](int slot, f32x4_t (&s)[2][NKB]) {
+        const char* Kb = smem_raw + slot * 2 * TILE_B;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            s[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            s[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int r = kb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Kb + r * ROWB + (((ks * 4 + grp) ^ (r & (CPR - 1))) << 4));
+                s[0][kb] = AttnMma<T>::run(kf, qf[0][ks], s[0][kb]);
+                s[1][kb] = AttnMma<T>::run(kf, qf[1][ks], s[1][kb]);
+            }
+        }
+    };
+
+    // softmax numerators of tile t from its scores + O^T += V^T P^T, l += 1^T P^T (v3's statements, unchanged)
+    auto softmax_pv = [&](int t, int slot, f32x4_t (&s)[2][NKB]) {
+        const char* Vb = smem_raw + slot * 2 * TILE_B + TILE_B;
+        const int t0 = t * kBKV;
+        uint4 pfrag[2][NKB / 2];
+        const bool need_mask = a.causal_br || (t0 + kBKV > kvl);   // wave-uniform
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kg = t0 + kb * 16 + grp * 4 + r;
+                        const bool ok = kg < kvl && (!a.causal_br || kg <= qi[qb] + shift);
+                        s[qb][kb][r] = ok ? s[qb][kb][r] : -1e30f;
+                    }
+            }
+            float tmax;
+            asm volatile("s_nop 7\n\ts_nop 7\n\tv_max3_f32 %0, %1, %2, %3"
+                         : "=v"(tmax) : "v"(s[qb][0][0]), "v"(s[qb][0][1]), "v"(s[qb][0][2]));
+            tmax = max3_asm(tmax, s[qb][0][3], s[qb][1][0]);
+#pragma unroll
+            for (int kb = 1; kb < NKB; ++kb) {
+                tmax = max3_asm(tmax, s[qb][kb][1], s[qb][kb][2]);
+                if (kb + 1 < NKB) tmax = max3_asm(tmax, s[qb][kb][3], s[qb][kb + 1][0]);
+                else tmax = max3_asm(tmax, s[qb][kb][3], s[qb][kb][3]);
+            }
+            if (__any(tmax > m_run[qb] + thr_raw)) {
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
+                m_run[qb] = m_new;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osum[qb][r] *= alpha;
+            }
+            const float nm = -fmaxf(m_run[qb], -1e29f) * sl2;
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+                float pf[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2][r], sl2, nm));
+                    pf[4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2 + 1][r], sl2, nm));
+                }
+                pfrag[qb][kp2] = pack<T>(pf);
+            }
+        }
+#pragma unroll
+        for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+            osum[0] = AttnMma<T>::run(ones, pfrag[0][kp2], osum[0]);
+            osum[1] = AttnMma<T>::run(ones, pfrag[1][kp2], osum[1]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const char* vb = Vb + voff[db] + kp2 * 32 * ROWB;
+                const v4s_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vb));
+                const v4s_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vb + 16 * ROWB));
+                const uint2 w0 = __builtin_bit_cast(uint2, v0), w1 = __builtin_bit_cast(uint2, v1);
+                const uint4 vfrag = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                o[0][db] = AttnMma<T>::run(vfrag, pfrag[0][kp2], o[0][db]);
+                o[1][db] = AttnMma<T>::run(vfrag, pfrag[1][kp2], o[1][db]);
+            }
+        }
+    };
+
+    if constexpr (!PIPE) {               // v3's loop order with the loop-invariant DMA addresses
+        issue_tile(0, 0);
+        if (1 < ntiles) issue_tile(1, 1);
+        int stage = 0;
+        f32x4_t sc[2][NKB];
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");   // tile t landed, t+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + NSTAGE - 1 < ntiles) {
+                int ns = stage + NSTAGE - 1;
+                if (ns >= NSTAGE) ns -= NSTAGE;
+                issue_tile(t + NSTAGE - 1, ns);
+            }
+            compute_s(stage, sc);
+            softmax_pv(t, stage, sc);
+            if (++stage == NSTAGE) stage = 0;
+        }
+    } else {
+    // ---- prologue: tiles 0 and 1 requested, S(0) computed ----------------------------------------------------------
+    issue_tile(0, 0);
+    if (1 < ntiles) issue_tile(1, 1);
+    if (1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");     // tile 0 landed, tile 1 may fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4_t sA[2][NKB], sB[2][NKB];
+    compute_s(0, sA);
+
+    // iteration t (scores of tile t in `cur`): K(t+1) landed for every wave -> tile t+2 requested into the slot tile t-1
+    // left -> S(t+1) issued into `nxt` -> softmax(t), PV(t)
+    auto iteration = [&](int t, int slot, f32x4_t (&cur)[2][NKB], f32x4_t (&nxt)[2][NKB]) {
+        const bool more = t + 1 < ntiles;
+        int s1 = slot + 1; if (s1 >= NSTAGE) s1 -= NSTAGE;
+        int s2 = s1 + 1;   if (s2 >= NSTAGE) s2 -= NSTAGE;
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 (its only outstanding DMA) landed
+            __syncthreads();                                   // ... and everybody's; iteration t-1 is finished everywhere
+            if (t + 2 < ntiles) issue_tile(t + 2, s2);
+            compute_s(s1, nxt);
+        }
+        softmax_pv(t, slot, cur);
+    };
+    int t = 0, slot = 0;
+    while (true) {
+        iteration(t, slot, sA, sB);
+        if (++t >= ntiles) break;
+        if (++slot == NSTAGE) slot = 0;
+        iteration(t, slot, sB, sA);
+        if (++t >= ntiles) break;
+        if (++slot == NSTAGE) slot = 0;
+    }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qi[qb] >= a.q_len) continue;
+        const float l = osum[qb][0];         // every row of the ones-product is the row sum
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi[qb] * a.o_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int d = db * 16 + grp * 4;
+            if (d + 3 < hd && ((a.o_ss | a.o_sh | a.o_sb) & 3) == 0) {
+                float pk[8] = {o[qb][db][0] * inv, o[qb][db][1] * inv, o[qb][db][2] * inv, o[qb][db][3] * inv, 0, 0, 0, 0};
+                const uint4 u = pack<T>(pk);
+                *reinterpret_cast<uint2*>(op + d) = make_uint2(u.x, u.y);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (d + r < hd) Tr<T>::st(op + d + r, o[qb][db][r] * inv);
+            }
+        }
+    }
+}
+
+template <typename T, bool PIPE>
+static int flash3p_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    const size_t lds = (size_t)3 * 2 * kBKV * 64 * 2;   // ring of 3 (K, V) tiles
+    const int nqb = cdiv(a.q_len, 128);
+    const int64_t bh = batch * a.n_heads;
+    AttnArgs a2 = a;
+    dim3 grid((unsigned)nqb, (unsigned)bh);
+    a2.xcd_heads = 0;
+    if (bh % 8 == 0 && nqb > 1 && tuning_get("attn_xcd", 1)) {
+        a2.xcd_heads = nqb;
+        grid = dim3((unsigned)(nqb * bh), 1);
+    }
+    hipLaunchKernelGGL((flash_attn3p_kernel<T, 64, PIPE>), grid, dim3(256), lds, s, a2);
+    SS_LAUNCH_CHECK("flash_attn3p");
+    return SS_OK;
+}
+
 template <typename T, int HD, bool VSWZ>
 static int flash3_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     const size_t lds = (size_t)(HD <= 64 ? 3 : 2) * 2 * kBKV * HD * 2;   // ring of (K, V) tiles
@@ -764,10 +1085,12 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     if constexpr (V == 8) {
         // v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill its 128-row blocks
         // v3 / v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill their 128-row blocks.
-        // attn_ver: 3 = v3 with the swizzled V image (default), 4 = v3 with the linear V image, 2 = v2
+        // attn_ver: 3 = v3 with the swizzled V image (default), 4 = v3 with the linear V image, 2 = v2, 5 / 6 = v3p with / without the S(t+1) prefetch (head_dim <= 64; else v3)
         const int ver = tuning_get("attn_ver", 3);
+        if (ver == 5 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, true>(a, batch, s);     // options: v3p (see (1d))
+        if (ver == 6 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, false>(a, batch, s);
         if (ver >= 3 && a.q_len >= 32) {
-            if (ver == 3) {
+            if (ver == 3 || ver >= 5) {
                 if (a.hd <= 64) return flash3_launch_hd<T, 64, true>(a, batch, s);
                 return flash3_launch_hd<T, 128, true>(a, batch, s);
             }

@@ -105,7 +105,7 @@ def timed(fn, n=10, warm=2):
 def cmd_attn():
     res = []
     dt = torch.bfloat16
-    for (B, Hh, hd, L, causal) in [(8, 10, 64, 4096, False), (8, 20, 64, 1024, False), (2, 10, 64, 4096, False),
+    for (B, Hh, hd, L, causal) in [(16, 10, 64, 4096, False), (16, 20, 64, 1024, False), (8, 10, 64, 4096, False), (8, 20, 64, 1024, False), (2, 10, 64, 4096, False),
                                    (1, 16, 104, 1024, False), (1, 32, 128, 343, True), (1, 32, 128, 913, True)]:
         E = Hh * hd
         q = torch.randn(B, L, E, device=DEV, dtype=dt)
@@ -113,7 +113,7 @@ def cmd_attn():
         v = torch.randn(B, L, E, device=DEV, dtype=dt)
         row = {"B": B, "heads": Hh, "hd": hd, "L": L, "causal": causal}
         flops = 4.0 * B * Hh * L * L * hd * (0.5 if causal else 1.0)
-        for ver, xcd in ((2, 0), (3, 0), (3, 1)):
+        for ver, xcd in ((2, 0), (3, 0), (3, 1), (6, 1), (5, 1)):      # 5 / 6: the v3p options (head_dim 64 only; else they run v3)
             _lib.set_tuning("attn_ver", ver)
             _lib.set_tuning("attn_xcd", xcd)
             us = min(timed(lambda: ops.attention(q, k, v, Hh, None, causal), n=8) for _ in range(3))
