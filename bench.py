@@ -853,10 +853,17 @@ def main():
                     help="A/B: run the 128 < M <= 512 LLaMA projections (stacked image-token block, first prompts) through the "
                          "regular GEMM tiles instead of the split-K weight-streaming path")
     ap.add_argument("--save-tune-table", default=None, help="write the GEMM tile table of this run to this JSON path")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
+                    help="A/B runs: set a library tuning knob before anything is built (e.g. --knob attn_ver=6); recorded in "
+                         "config.knobs — a line with knobs is not the shipped configuration")
     args = ap.parse_args()
     if args.max_slots:
         global MAX_SLOTS
         MAX_SLOTS = max(1, min(8, args.max_slots))
+    knobs = {}
+    for kv in args.knob:
+        name, _, val = kv.partition("=")
+        knobs[name.strip()] = int(val)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -880,6 +887,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = torch.bfloat16
+    if knobs:
+        from seedstory import _lib as _lk
+        for name, val in knobs.items():
+            _lk.set_tuning(name, val)
     if args.no_splitk:
         from seedstory import _lib as _l
         _l.set_tuning("gemm_splitk", 0)
@@ -1010,7 +1021,7 @@ def main():
                "overlap_fallback": runner.overlap_fallback is not None, "overlap_fallback_error": runner.overlap_fallback,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": workload, "unet_linear_dtype": "fp8_e4m3" if args.unet_fp8 else "bf16", "diffusion_steps": None if args.mllm_only else args.diffusion_steps,
-                          "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN,
+                          "kv_reuse": bool(args.kv_reuse), "tokens_per_step": T_GEN, "knobs": knobs or None,
                           "img_block_decode": bool(eng.img_block_enabled()),
                           "img_block_decode_note": "the 65 tokens the logits processor forces behind <img> are fed as ONE stacked "
                                                    "continuation for all lock-step slots of a decode group (same layers / attention "
