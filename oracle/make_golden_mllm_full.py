@@ -9,7 +9,7 @@ story3_truth}` — O.vit_forward / O.llama_forward / O.resampler_forward on seed
 Each file is keyed on a fingerprint of the weights and ids it was computed from: a box that draws the same seeded weights loads
 it, any other box recomputes the truth on its host as before.  One part per process (the 7B weights take 40 GB of host memory):
 
-    python oracle/make_golden_mllm_full.py            # all three, ~15 min on 8 cores
+    python oracle/make_golden_mllm_full.py            # all three, ~7 min on 8 cores (62 GB of host memory is enough)
     python oracle/make_golden_mllm_full.py llama7b    # one part
 """
 import os
