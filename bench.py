@@ -717,6 +717,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": ff1_traffic,
                 "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
                 "traffic_note": traffic_note, "tile_table_sha16": table_sha,
+                "pmc_record_tile_table_sha16": pmcj.get("tile_table_sha16"),    # (the table the counters ran on; rows are matched per shape + tile)
                 "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
                 "sustained_ceiling": {"value": 1300.0, "unit": "TFLOP/s", "frac_of_ceiling": round(flops / (ms * 1e-3) / 1.3e15, 4),
                                       "note": "what this part sustains on RANDOM bf16 operands (power-limited clock: 8192^3 GEMM at MFMA busy "
