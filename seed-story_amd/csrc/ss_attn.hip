@@ -248,6 +248,7 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, uint32_t lds_base) 
         : "memory");
 }
 
+#if SS_EXPERIMENTAL   // v2 (round 2; superseded by v3 / v3p, selected by no default): `make EXPERIMENTAL=1` keeps it for A/B runs
 template <typename T, int HD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD <= 64 ? 3 : 2)))
 void flash_attn2_kernel(const AttnArgs a) {
@@ -456,6 +457,7 @@ void flash_attn2_kernel(const AttnArgs a) {
         }
     }
 }
+#endif  // SS_EXPERIMENTAL
 
 // --------------------------------------------------------------------------------------------
 // (1c) flash attention v3 (bf16 / f16): the v2 data path (32 query rows per wave, K/V tiles by LDS-DMA in a ring,
@@ -716,7 +718,10 @@ void flash_attn3_kernel(const AttnArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// (1d) flash attention v3p — OPTION (tuning knob attn_ver = 5: PIPE, 6: addresses only; head_dim <= 64), not the shipped default.
+// (1d) flash attention v3p (head_dim <= 64).  attn_ver = 6 (addresses only, PIPE = false) is the SHIPPED DEFAULT since round 5
+//   (validated on MI355X: bit-equal to v3 on every shape class of tests/test_kernels_gpu.py::test_flash_v3p_equals_v3 and against
+//   the fp32 oracle in test_sdxl_attention_shapes_bf16; 863 -> 837 us at (16, 10 heads, 4096), 116.5 -> 112.1 us at (16, 20, 1024));
+//   attn_ver = 5 (PIPE) stays an option: measured SLOWER than v3 (859 / 122 us) — the 204-VGPR form drops to 2 waves per SIMD.
 //   Same data path, softmax and fragment layouts as v3 with the two changes the instruction budget of v3 asks for
 //   (per 64-key tile and wave 1152 matrix-pipe cycles against ~1190 VALU cycles, MFMA busy 0.34-0.41):
 //   * S(t+1) = K(t+1) Q^T is ISSUED before the softmax of tile t: the 16 S MFMAs of the next tile run on the matrix pipe
@@ -1053,6 +1058,7 @@ static int flash3_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     return SS_OK;
 }
 
+#if SS_EXPERIMENTAL
 template <typename T, int HD>
 static int flash2_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     const size_t lds = (size_t)(HD <= 64 ? 3 : 2) * 2 * kBKV * HD * 2;   // ring of (K, V) tiles
@@ -1061,6 +1067,7 @@ static int flash2_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
     SS_LAUNCH_CHECK("flash_attn2");
     return SS_OK;
 }
+#endif
 
 template <typename T, int HD>
 static int flash_launch_hd(const AttnArgs& a, int64_t batch, hipStream_t s) {
@@ -1085,8 +1092,11 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     if constexpr (V == 8) {
         // v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill its 128-row blocks
         // v3 / v2 (DMA-staged, 32 rows per wave) whenever there is enough query work to fill their 128-row blocks.
-        // attn_ver: 3 = v3 with the swizzled V image (default), 4 = v3 with the linear V image, 2 = v2, 5 / 6 = v3p with / without the S(t+1) prefetch (head_dim <= 64; else v3)
-        const int ver = tuning_get("attn_ver", 3);
+        // attn_ver: 6 (default since round 5) = v3p without the S(t+1) prefetch for head_dim <= 64 (loop-invariant DMA addresses;
+        // measured -3 ... -4 % per launch on the UNet's self-attention shapes and bit-equal to v3, profiles/round5_attn_ab.json),
+        // v3 for head_dim 128; 3 = v3 with the swizzled V image everywhere, 4 = v3 with the linear V image,
+        // 5 = v3p WITH the prefetch (measured slower than v3: 2 waves per SIMD)
+        const int ver = tuning_get("attn_ver", 6);
         if (ver == 5 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, true>(a, batch, s);     // options: v3p (see (1d))
         if (ver == 6 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, false>(a, batch, s);
         if (ver >= 3 && a.q_len >= 32) {
@@ -1097,10 +1107,14 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
             if (a.hd <= 64) return flash3_launch_hd<T, 64, false>(a, batch, s);
             return flash3_launch_hd<T, 128, false>(a, batch, s);
         }
+#if SS_EXPERIMENTAL
         if (ver == 2 && a.q_len >= 32) {
             if (a.hd <= 64) return flash2_launch_hd<T, 64>(a, batch, s);
             return flash2_launch_hd<T, 128>(a, batch, s);
         }
+#else
+        SS_REQUIRE(ver != 2, "attention: attn_ver 2 (flash v2) is only in the EXPERIMENTAL=1 build");
+#endif
     }
     if (a.hd <= 64) return flash_launch_hd<T, 64>(a, batch, s);
     return flash_launch_hd<T, 128>(a, batch, s);

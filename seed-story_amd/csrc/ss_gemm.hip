@@ -20,8 +20,17 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
 
 // Register-staged kernel: global -> register -> LDS staging with the next tile's loads in flight during the MFMAs
 // (guide T14 write-late form), padded LDS rows (+1 pack) to break the 128-byte stride.
-template <typename T, int BM, int BN, int WM, int WN, int KT, bool CONV>
+//
+// SPLIT (fp32 tensors only; tuning knob `gemm_f32_split`, the "gate mode" of DESIGN §5): the fp32 operands are split on their
+// way into LDS, x = hi + lo with hi = bf16(x) and lo = bf16(x - hi) (x - hi is exact in fp32), and the product is formed on the
+// bf16 matrix pipe as  A·W^T ~= Ahi·Whi^T + Ahi·Wlo^T + Alo·Whi^T  with fp32 accumulation — three v_mfma_f32_16x16x32_bf16 per
+// fragment pair and 32 k instead of eight v_mfma_f32_16x16x4_f32 at 1/16 of the rate.  The dropped Alo·Wlo term and the
+// 16-bit operand mantissas leave a relative error of ~2^-17 per product (random sign): ~1e-5 per GEMM against the exact fp32 FMA
+// chain, two orders inside the 1e-3 gate on the regressed image features.  Same tile, same LDS footprint (a row is 64 B of
+// hi + 64 B of lo + one 16-byte pad instead of 128 B of fp32 + pad), same loads, same epilogue.
+template <typename T, int BM, int BN, int WM, int WN, int KT, bool CONV, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
+    static_assert(!SPLIT || (Tr<T>::kVec == 4 && KT == 1), "SPLIT: fp32 operands, one 32-wide k tile");
     constexpr int V = Tr<T>::kVec;
     constexpr int NT = 64 * WM * WN;     // threads per block
     constexpr int PPR = 8 * KT;          // packs per tile row
@@ -94,16 +103,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             rw[i] = (p < BN * PPR && n < N && k < K) ? ld16(W + (int64_t)n * g.ldw + k) : make_uint4(0, 0, 0, 0);
         }
     };
+    // SPLIT: pack c of a row (k = 4c .. 4c+3) -> 8 bytes of hi at byte 8c and 8 bytes of lo at byte 64 + 8c of the row
+    auto split_store = [&](char* row, int c, const uint4& u) {
+        const float x0 = __uint_as_float(u.x), x1 = __uint_as_float(u.y), x2 = __uint_as_float(u.z), x3 = __uint_as_float(u.w);
+        const uint32_t h01 = f32x2_to_bf16x2_bits(x0, x1), h23 = f32x2_to_bf16x2_bits(x2, x3);
+        const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
+        const float r2 = x2 - __uint_as_float(h23 << 16), r3 = x3 - __uint_as_float(h23 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(row + c * 8) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(row + 64 + c * 8) = make_uint2(f32x2_to_bf16x2_bits(r0, r1), f32x2_to_bf16x2_bits(r2, r3));
+    };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int p = tid + i * NT;
-            if (p < BM * PPR) st16(As + (p / PPR) * LS + (p % PPR) * V, ra[i]);
+            if (p < BM * PPR) {
+                if constexpr (SPLIT) split_store(reinterpret_cast<char*>(As + (p / PPR) * LS), p % PPR, ra[i]);
+                else st16(As + (p / PPR) * LS + (p % PPR) * V, ra[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int p = tid + i * NT;
-            if (p < BN * PPR) st16(Ws + (p / PPR) * LS + (p % PPR) * V, rw[i]);
+            if (p < BN * PPR) {
+                if constexpr (SPLIT) split_store(reinterpret_cast<char*>(Ws + (p / PPR) * LS), p % PPR, rw[i]);
+                else st16(Ws + (p / PPR) * LS + (p % PPR) * V, rw[i]);
+            }
         }
     };
 
@@ -112,7 +136,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         store_tile();
         __syncthreads();
         if (t + 1 < ntiles) load_tile(t + 1);  // in flight while the MFMAs run
-        if constexpr (V == 8) {
+        if constexpr (SPLIT) {
+            uint4 fwh[FN], fwl[FN], fah[FM], fal[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const char* r = reinterpret_cast<const char*>(Ws + (wn * TN + i * 16 + l15) * LS) + grp * 16;
+                fwh[i] = *reinterpret_cast<const uint4*>(r);
+                fwl[i] = *reinterpret_cast<const uint4*>(r + 64);
+            }
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const char* r = reinterpret_cast<const char*>(As + (wm * TM + j * 16 + l15) * LS) + grp * 16;
+                fah[j] = *reinterpret_cast<const uint4*>(r);
+                fal[j] = *reinterpret_cast<const uint4*>(r + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {       // the two cross terms first, the leading term last
+                    acc[i][j] = Mma<bf16_t>::run(fwl[i], fah[j], acc[i][j]);
+                    acc[i][j] = Mma<bf16_t>::run(fwh[i], fal[j], acc[i][j]);
+                    acc[i][j] = Mma<bf16_t>::run(fwh[i], fah[j], acc[i][j]);
+                }
+        } else if constexpr (V == 8) {
 #pragma unroll
             for (int ks = 0; ks < BK / 32; ++ks) {
                 uint4 fw[FN], fa[FM];
@@ -197,6 +243,16 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int LS = 8 * KT * V + V;
     const size_t lds = (size_t)(BM + BN) * LS * sizeof(T);
     dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
+    if constexpr (V == 4 && KT == 1) {      // fp32 tensors: the split-bf16 "gate mode" instead of the exact fp32 FMA chain
+        if (tuning_get("gemm_f32_split", 0)) {
+            if (g.conv_Cin > 0)
+                hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, KT, true, true>), grid, dim3(64 * WM * WN), lds, s, g);
+            else
+                hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, KT, false, true>), grid, dim3(64 * WM * WN), lds, s, g);
+            SS_LAUNCH_CHECK("gemm_split");
+            return SS_OK;
+        }
+    }
     if (g.conv_Cin > 0)
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, KT, true>), grid, dim3(64 * WM * WN), lds, s, g);
     else
@@ -731,11 +787,16 @@ int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_
         int cfg = lookup_cfg<T>(g);
         if (cfg < 60 || cfg > 72) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : (M * N >= 128 * 128 * 256 ? 65 : 70);
         // Round 4: the folded epilogue runs on the 8-wave tiles only.  On the 4-wave tiles (61 / 65 / 67 / 68 / 70: two
-        // workgroups per CU) it sporadically returns ONE wrong element per 16-row strip of the last fragment column of a wave
+        // workgroups per CU) it sporadically returned ONE wrong element per 16-row strip of the last fragment column of a wave
         // (tools/dbg_lnfold_vec.py: 16-128 bad rows per 4 launches at [32768, 640, 640]; the plain epilogue on the same tiles and
-        // the folded one on the 8-wave tiles: none in the same runs) — cause not found, so those tiles are not offered.
-        if (cfg == 61 || cfg == 67) cfg = 62;
-        else if (cfg == 65 || cfg == 68 || cfg == 70) cfg = N % 160 == 0 ? 62 : 66;
+        // the folded one on the 8-wave tiles: none in the same runs).  The accumulator fences behind the K loop
+        // (ss_gemm_sp.inc, "MFMA results settle before VALU reads them") were added afterwards for exactly this signature; the
+        // reroute stays until tools/dbg_lnfold_vec.py has re-checked the 4-wave tiles WITH the fences (`lnfold_w4` = 1 offers
+        // them again for that check; status of the re-check: DESIGN §4, LayerNorm-fold row).
+        if (!tuning_get("lnfold_w4", 0)) {
+            if (cfg == 61 || cfg == 67) cfg = 62;
+            else if (cfg == 65 || cfg == 68 || cfg == 70) cfg = N % 160 == 0 ? 62 : 66;
+        }
         const int rc = gemm_sp_dispatch<T>(cfg + 100, g, s);
         if (rc == 1) {
             set_error("ss_gemm_lnfold: no kernel for cfg %d / shape [%lld, %lld, %lld]", cfg + 100, (long long)M, (long long)N, (long long)K);

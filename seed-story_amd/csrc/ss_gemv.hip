@@ -648,7 +648,9 @@ __global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, 
         });
         load_chunk(std::integral_constant<int, 0>{}, tile);
     }
-    const bool vec_ok = ((a.y_ld | a.res_ld | N) & 3) == 0 && N >= 4 && (a.epi & (SS_EPI_RESIDUAL | SS_EPI_BIAS));
+    // 8-byte epilogue accesses need 8-byte aligned BASES too (a bias / residual view at an odd element offset)
+    const bool vec_ok = ((a.y_ld | a.res_ld | N) & 3) == 0 && N >= 4 && (a.epi & (SS_EPI_RESIDUAL | SS_EPI_BIAS)) &&
+                        ((((size_t)a.y | (size_t)a.residual | (size_t)a.bias) & 7) == 0);
 
     // one row tile: per chunk — next chunk requested (the next TILE's first chunk behind the last one), this chunk consumed;
     // then partial sums to LDS, barrier, wave 0 folds the 8 slices and stores

@@ -495,7 +495,7 @@ void* ss_llama_buffer(ss_llama* h, int which) {
 }
 
 int ss_llama_set_lengths(ss_llama* h, int64_t kv_len, int64_t pos, void* stream) {
-    SS_REQUIRE(h && kv_len >= 0 && kv_len <= h->cfg.cache_cap && pos >= 0 && pos < h->cfg.max_pos,
+    SS_REQUIRE(h && kv_len >= 0 && kv_len <= h->cfg.cache_cap && pos >= 0 && pos <= h->cfg.max_pos,
                "llama_set_lengths: out of range (kv_len=%lld pos=%lld)", (long long)kv_len, (long long)pos);
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->state + (size_t)h->cur * 8,
                        (int)ST_KV_LEN, (int)kv_len, (int)ST_POS, (int)pos);
@@ -613,7 +613,9 @@ int ss_llama_prefill_batch(ss_llama* h, const void* embeds, const int64_t* host_
                    (long long)h->kv_len[b], (long long)r, g.cache_cap);
         // (the bound of ss_llama_set_lengths, checked for EVERY slot before anything is launched: a slot that fails there
         // after the forward would leave host and device lengths inconsistent across the slots)
-        SS_REQUIRE(r == 0 || h->pos[b] + r < g.max_pos, "llama_prefill_batch: position overflow in slot %d (%lld + %lld >= %d)", b,
+        // (`<=`: the last RoPE position used is pos + r - 1, so a prompt may exactly fill the position table — the same bound as
+        // the single-slot ss_llama_prefill; decoding further is refused by the generate entry points)
+        SS_REQUIRE(r == 0 || h->pos[b] + r <= g.max_pos, "llama_prefill_batch: position overflow in slot %d (%lld + %lld > %d)", b,
                    (long long)h->pos[b], (long long)r, g.max_pos);
         M += r;
     }
@@ -719,6 +721,8 @@ int ss_llama_generate(ss_llama* h, int64_t n_steps, int32_t last_prompt_id, cons
     SS_REQUIRE(n_forced >= 0 && n_forced <= g.max_new, "llama_generate: n_forced out of range");
     SS_REQUIRE(h->kv_len[q] + limit <= g.cache_cap, "llama_generate: KV cache overflow (%lld + %lld > %d)",
                (long long)h->kv_len[q], (long long)limit, g.cache_cap);
+    SS_REQUIRE(h->pos[q] + limit <= g.max_pos, "llama_generate: position overflow (%lld + %lld > %d)", (long long)h->pos[q],
+               (long long)limit, g.max_pos);
     if (n_forced > 0)
         SS_HIP(hipMemcpyAsync(h->forced + (size_t)q * g.max_new, host_forced, (size_t)n_forced * sizeof(int32_t),
                               hipMemcpyHostToDevice, s));
@@ -745,6 +749,8 @@ int ss_llama_generate_batch(ss_llama* h, int64_t n_steps, const int32_t* last_pr
         SS_REQUIRE(!on || h->kv_len[b] + limit <= g.cache_cap,
                    "llama_generate_batch: KV cache overflow in slot %d (%lld + %lld > %d)", b, (long long)h->kv_len[b],
                    (long long)limit, g.cache_cap);
+        SS_REQUIRE(!on || h->pos[b] + limit <= g.max_pos, "llama_generate_batch: position overflow in slot %d (%lld + %lld > %d)",
+                   b, (long long)h->pos[b], (long long)limit, g.max_pos);
         const int32_t* f = host_forced ? host_forced + (size_t)b * forced_ld : nullptr;
         if (on && nf > 0)
             SS_HIP(hipMemcpyAsync(h->forced + (size_t)b * g.max_new, f, (size_t)nf * sizeof(int32_t),

@@ -333,12 +333,15 @@ class UNet2DConditionModel(nn.Module):
 
     def enable_lnfold(self, on=True):
         """Fold norm1 / norm2 / norm3 of every transformer block into the GEMM that follows (q|k|v, to_q, GEGLU ff1):
-        the GEMM streams the raw rows and its epilogue applies the per-row statistics (`ss_gemm_lnfold`); the statistics
-        are accumulated by the epilogue of the GEMM that PRODUCED the rows (`ss_gemm_rowstat` + `ss_rowstat_finalize`), so
-        the three LayerNorm launches, their normalised tensors and every statistics pass disappear.  16-bit path only (fp8
-        fuses the LayerNorm into its quantiser instead; fp32 runs the plain LayerNorm).  OFF by default: measured on MI355X
-        (profiles/round3_lnfold_rowstat_ab.txt) the forward is 66.4 ms either way — the 3.2 ms of LayerNorm launches are
-        traded for 0.9 ms of ss_rowstat_finalize launches and a ~4 % slower folded epilogue on the q|k|v / ff1 GEMMs."""
+        the GEMM streams the raw rows and its epilogue applies the per-row statistics.  The statistics are per-strip
+        (sum, sum of squares) partials written by the epilogue of the GEMM that PRODUCED the rows (`ss_gemm_rowpart`: no
+        atomics) and folded in a fixed order by the consumer's epilogue (`ss_gemm_lnfold_part`: no finalize launch); where
+        the producer's tile is not eligible, a statistics pass (`ss_rowstats` + `ss_gemm_lnfold`).  16-bit path only (fp8
+        fuses the LayerNorm into its quantiser instead; fp32 runs the plain LayerNorm).  OFF by default: on MI355X the
+        forward does not get faster either way (round 3, atomic form: 66.4 ms on and off, profiles/round3_lnfold_rowstat_ab.txt;
+        round 4, strip form: still +-0) — the LayerNorm launches are traded for a slower folded epilogue on
+        the q|k|v / ff1 GEMMs.  (The round-3 `ss_gemm_rowstat` + `ss_rowstat_finalize` atomic form is legacy API: kept in
+        the C ABI with its test, no caller in the model.)"""
         if bool(on) != getattr(self, "_lnfold", False):
             self._lnfold = bool(on)
             self._prep = None
@@ -544,8 +547,11 @@ class AutoencoderKL(nn.Module):
     fp32, because its activations overflow fp16 at 1024 px — gen_george.py:62 + StableDiffusionXLPipeline):
       * bf16 module -> bf16 decode (fp32's exponent range: no overflow; tests/test_fulldim_gpu.py::
         test_vae_decode_full_size_pixel_parity measures the uint8 deviation from the fp32 reference);
-      * fp16 module with ``force_upcast`` (the reference's default dtype) -> decoded in **bf16**, never in fp16;
-      * ``set_tuning("vae_fp32", 1)`` -> decoded in fp32 (exact-fp32 MFMA path: the reference's arithmetic, ~8x slower)."""
+      * fp16 module with ``force_upcast`` (the reference scripts' default dtype, gen_george.py:19) -> decoded in
+        **fp32**, which is what diffusers does (``needs_upcasting = vae.dtype == float16 and config.force_upcast``);
+        ``set_tuning("vae_bf16", 1)`` opts into the 7x faster bf16 decode for that case (fp32's exponent range, so no
+        overflow, but narrower arithmetic than the reference: uint8 mean deviation 0.57, max 5-6) — never fp16;
+      * ``set_tuning("vae_fp32", 1)`` -> decoded in fp32 whatever the module dtype (exact-fp32 MFMA path)."""
 
     def __init__(self, config=None):
         super().__init__()
@@ -588,7 +594,7 @@ class AutoencoderKL(nn.Module):
         if _lib.get_tuning("vae_fp32", 0):
             return torch.float32
         if p0 == torch.float16 and self.config.force_upcast:
-            return torch.bfloat16
+            return torch.bfloat16 if _lib.get_tuning("vae_bf16", 0) else torch.float32
         return p0
 
     def _prepare(self, run_dtype=None):

@@ -243,7 +243,10 @@ def gemm_lnfold(x, wg, rstd, shift, colsum, bias_d=None, gelu=False, geglu=False
 
 
 def rowpart_strips(M, N, K, dtype):
-    """Number of (sum, sum of squares) partials per row that ``gemm(..., rowpart=)`` writes for this shape (0: not eligible)."""
+    """Number of (sum, sum of squares) partials per row that ``gemm(..., rowpart=)`` writes for this shape (0: not eligible).
+    The answer depends on the tile the table holds for the shape, so the shape is tuned FIRST (a first forward on a
+    shape absent from the table used to size the strip buffer from the closed-form tile and then re-tune inside `gemm`)."""
+    tune.ensure_gemm(M, N, K, dt(dtype), 0, None)
     return int(lib().ss_gemm_rowpart_strips(M, N, K, dt(dtype)))
 
 

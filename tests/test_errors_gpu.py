@@ -74,6 +74,28 @@ def test_engine_capacity_errors_and_recovery(golden):
                     dtype=torch.float32, device=DEV, cache_cap=48, max_new=8, max_prefill_rows=32, img_ids=[], n_seq=9)          # 1..8 slots
 
 
+def test_prompt_may_fill_the_position_table_exactly(golden):
+    """the last RoPE position a prefill uses is pos + rows - 1, so a prompt of exactly max_pos rows is legal on the
+    single-slot AND the stacked path (which used to refuse it), with the same hidden rows; decoding past the table is refused."""
+    from seedstory.llama import LlamaEngine
+    g, meta = golden
+    d = meta["LLAMA"]
+    wd = synth.llama_weights(11, d["hidden"], d["n_heads"], d["n_layers"], d["inter"], d["vocab"])
+    kw = dict(hidden=d["hidden"], n_heads=d["n_heads"], n_layers=d["n_layers"], inter=d["inter"], vocab=d["vocab"],
+              dtype=torch.float32, device=DEV, cache_cap=48, max_new=8, max_prefill_rows=64, img_ids=list(range(254, 320)), max_pos=24)
+    emb = wd["model.embed_tokens.weight"]
+    ids = synth.randint(1, (25,), 3, 250)
+    one = LlamaEngine(wd, **kw)
+    h1 = one.prefill(emb[ids[:24]], want_hidden=True).clone()
+    assert one.lengths() == (24, 24)
+    _err(lambda: one.generate(1, last_prompt_id=int(ids[23])), "position overflow")
+    two = LlamaEngine(wd, n_seq=2, **kw)
+    hb = two.prefill_batch([emb[ids[:24]], emb[ids[:10]]], want_hidden=True)
+    assert torch.equal(hb[0], h1)
+    _err(lambda: two.prefill_batch([None, emb[ids[:15]]]), "position overflow in slot 1 (10 + 15 > 24)")
+    _err(lambda: one.prefill(emb[ids[:1]]), "position overflow")
+
+
 def test_preprocess_and_misc_argument_errors():
     from seedstory import _lib, preprocess
     pp = preprocess.DevicePreprocessor((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 64, device=DEV, dtype=BF)

@@ -2,9 +2,10 @@
 written without a GPU at hand (round 4 ended with the GPU budget spent) and are validated here before a later round adopts any of
 them; the round-end `pytest -m gpu` must not depend on them.
 
-  * flash attention v3p (`attn_ver` 5 = S(t+1) prefetch + loop-invariant DMA addresses, 6 = addresses only; csrc/ss_attn.hip (1d)):
-    same arithmetic per score as the shipped v3 -> outputs must be EQUAL to v3's, bit for bit, on every head-dim-64 shape class
-    (self-attention with many tiles, cross-attention with one tile, ragged tails in q and kv, bottom-right causal)."""
+  * flash attention v3p with the S(t+1) prefetch (`attn_ver` 5; csrc/ss_attn.hip (1d)): same arithmetic per score as v3 -> outputs
+    must be EQUAL to v3's, bit for bit, on every head-dim-64 shape class (self-attention with many tiles, cross-attention with one
+    tile, ragged tails in q and kv, bottom-right causal).  Round 5 ran these on MI355X (37 passed) and measured the option SLOWER
+    than v3; `attn_ver` 6 (addresses only) won, became the default, and its equality test moved to tests/test_kernels_gpu.py."""
 import os
 
 import pytest
@@ -15,7 +16,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("SS_TEST_EX
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("ver", [5, 6])
+@pytest.mark.parametrize("ver", [5])
 @pytest.mark.parametrize("B,heads,Lq,Lk,causal", [(16, 10, 4096, 4096, False), (16, 20, 1024, 1024, False), (16, 20, 1024, 64, False),
                                                  (3, 5, 1000, 1000, False), (2, 3, 130, 77, False), (1, 4, 64, 64, False),
                                                  (2, 4, 333, 333, True), (1, 8, 200, 913, True), (1, 2, 33, 4096, True)])
@@ -34,7 +35,7 @@ def test_flash_v3p_equals_v3(ver, B, heads, Lq, Lk, causal, dtype):
         try:
             outs[vv] = ops.attention(q, k, v, heads, None, causal).clone()
         finally:
-            _lib.set_tuning("attn_ver", 3)
+            _lib.set_tuning("attn_ver", 6)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(outs[ver].float()).all())
     assert torch.equal(outs[3], outs[ver]), float((outs[3].float() - outs[ver].float()).abs().max())
@@ -49,5 +50,5 @@ def test_flash_v3p_head_dim_128_falls_back_to_v3():
         try:
             outs.append(ops.attention(q, q, q, 32, None, True).clone())
         finally:
-            _lib.set_tuning("attn_ver", 3)
+            _lib.set_tuning("attn_ver", 6)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

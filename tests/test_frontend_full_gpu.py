@@ -28,6 +28,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DTYPES = [(torch.float32, "f32"), (torch.bfloat16, "bf16")]
+F32_TOL = [1e-4]      # fp32 tolerance of gate(); the split-bf16 "gate mode" tests below widen it to the north-star 1e-3
+
+
+class split_mode:
+    """`gemm_f32_split` = 1: every GEMM on fp32 tensors runs as three bf16 MFMA products on hi / lo operand halves with fp32
+    accumulation (csrc/ss_gemm.hip, SPLIT) instead of the exact 1/16-rate fp32 MFMA chain — the affordable mode that still
+    meets the 1e-3 gate on `img_gen_feat`."""
+
+    def __enter__(self):
+        from seedstory import _lib
+        _lib.set_tuning("gemm_f32_split", 1)
+        F32_TOL[0] = 1e-3
+
+    def __exit__(self, *a):
+        from seedstory import _lib
+        _lib.set_tuning("gemm_f32_split", 0)
+        F32_TOL[0] = 1e-4
 
 
 def rel(a, b):
@@ -57,12 +74,12 @@ def gate(name, y, g, tag_base, dtag, stride, oracle_f32=None):
     ref_nrm = float(g["%s_%s.norm" % (tag_base, dtag)])
     if dtag == "f32":
         print("%s fp32: HIP vs REFERENCE rows %.3e | norm %.6g vs %.6g" % (name, r_same, nrm, ref_nrm))
-        assert r_same < 1e-4, (name, r_same)
-        assert abs(nrm - ref_nrm) <= 1e-4 * ref_nrm
+        assert r_same < F32_TOL[0], (name, r_same)
+        assert abs(nrm - ref_nrm) <= F32_TOL[0] * ref_nrm
         if oracle_f32 is not None:
             r_full = rel(y, oracle_f32)
             print("%s fp32: HIP vs oracle, whole tensor %.3e" % (name, r_full))
-            assert r_full < 1e-4, (name, r_full)
+            assert r_full < F32_TOL[0], (name, r_full)
         return r_same
     r_32 = rel(rows, ref32)
     gap = rel(ref, ref32)
@@ -224,3 +241,25 @@ def test_generate_hidden4096_full_size_regressor(full, dtype, dtag):
         print("img_gen_feat bf16 vs the reference's fp32 rows: bf16 regressor %.3e | fp32 regressor on the bf16 rows %.3e"
               % (d_plain, d_mixed))
         assert d_mixed <= d_plain * 1.05 + 1e-3
+
+
+# ---- the gate mode: fp32 tensors, split-bf16 MFMA products (gemm_f32_split) — must meet the north-star 1e-3 vs the REAL rows ----
+
+@pytest.mark.parametrize("which", ["res_in", "res_out"])
+def test_gate_mode_resampler_4096_32heads(full, which):
+    with split_mode():
+        test_resampler_4096_32heads(full, which, torch.float32, "f32")
+
+
+def test_gate_mode_vit_ends_and_xlv2(full):
+    with split_mode():
+        test_vit_ends_real_size(full, torch.float32, "f32")
+        test_resampler_xlv2_real_config(full, torch.float32, "f32")
+
+
+def test_gate_mode_generate_hidden4096_img_gen_feat(full):
+    """The north-star quantity itself in the affordable gate mode: LLaMA-7B-width decoder layers (prefill through the split GEMM,
+    decode through the fp32-weight GEMV), full-size regressor — img_gen_feat <= 1e-3 against the REAL reference's fp32 rows and
+    the same generated ids."""
+    with split_mode():
+        test_generate_hidden4096_full_size_regressor(full, torch.float32, "f32")

@@ -611,10 +611,11 @@ def test_sdxl_conv_shapes_bf16(B, Hh, Ww, Cin, Cout, stride, up):
 
 
 @pytest.mark.parametrize("B,heads,L,Lk", [(UB, 10, 4096, 4096), (UB, 20, 1024, 1024), (UB, 10, 4096, 64), (UB, 20, 1024, 64)])
-@pytest.mark.parametrize("ver", [3, 4, 2])
+@pytest.mark.parametrize("ver", [6, 3, 4, 5])
 def test_sdxl_attention_shapes_bf16(B, heads, L, Lk, ver):
-    """UNet self- / cross-attention at head_dim 64 through each flash kernel generation (attn_ver 3 = swizzled V,
-    4 = linear V, 2 = previous kernel) vs fp32 softmax attention on the same bf16 q/k/v."""
+    """UNet self- / cross-attention at head_dim 64 through each flash kernel variant (attn_ver 6 = v3p, the shipped default
+    since round 5; 3 = v3 swizzled V; 4 = v3 linear V; 5 = v3p with the S(t+1) prefetch) vs fp32 softmax attention on the
+    same bf16 q/k/v."""
     from seedstory import _lib, ops
     dt = torch.bfloat16
     E = heads * 64
@@ -627,7 +628,7 @@ def test_sdxl_attention_shapes_bf16(B, heads, L, Lk, ver):
     try:
         y = ops.attention(q, k, v, heads)
     finally:
-        _lib.set_tuning("attn_ver", 3)
+        _lib.set_tuning("attn_ver", 6)
     err = 0.0
     for b in range(0, B, 3):                 # fp32 reference per batch element (scores of one element: 10 x 4096^2 fp32)
         qh = q[b].float().view(L, heads, 64).transpose(0, 1)

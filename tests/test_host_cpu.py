@@ -361,8 +361,9 @@ def test_pipeline_graph_cache_dies_with_its_buffers():
 
 
 def test_vae_decode_dtype_policy():
-    """ADVICE r1: the fp16 SDXL VAE is never decoded in fp16 (diffusers upcasts it: force_upcast); bf16 stays bf16;
-    vae_fp32 selects the reference's fp32 arithmetic."""
+    """The fp16 SDXL VAE with force_upcast (the reference scripts' dtype, gen_george.py:19,62) decodes in fp32 — what
+    diffusers does — and in bf16 only behind the `vae_bf16` opt-in, never in fp16; bf16 stays bf16 (diffusers does not
+    up-cast a bf16 VAE); vae_fp32 selects fp32 arithmetic for every module dtype."""
     import torch
     from seedstory import _lib
     from seedstory.diffusion import AutoencoderKL
@@ -370,7 +371,13 @@ def test_vae_decode_dtype_policy():
                norm_groups=32, scaling_factor=0.13025)
     v = AutoencoderKL(cfg)
     assert v.config.force_upcast is True
-    assert v.to(torch.float16).decode_dtype() == torch.bfloat16
+    assert v.to(torch.float16).decode_dtype() == torch.float32
+    _lib.set_tuning("vae_bf16", 1)
+    try:
+        assert v.to(torch.float16).decode_dtype() == torch.bfloat16
+        assert v.to(torch.float32).decode_dtype() == torch.float32          # the opt-in only concerns the fp16 case
+    finally:
+        _lib.set_tuning("vae_bf16", 0)
     assert v.to(torch.bfloat16).decode_dtype() == torch.bfloat16
     assert v.to(torch.float32).decode_dtype() == torch.float32
     v2 = AutoencoderKL(dict(cfg, force_upcast=False)).to(torch.float16)

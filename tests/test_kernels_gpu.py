@@ -225,6 +225,32 @@ def test_gemm(ops, M, N, K, dtype):
     assert rel(y, torch.nn.functional.gelu((ref + bias.float()).to(dtype))) < tol * 1.5, "bias+gelu"
 
 
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(528, 4096, 4096), (913, 12288, 4096)])
+def test_gemm_f32_split_bf16_gate_mode(ops, M, N, K):
+    """`gemm_f32_split`: fp32 tensors through three bf16 MFMA products on (hi, lo) operand halves with fp32 accumulation
+    (csrc/ss_gemm.hip SPLIT).  Against the fp64 product: <= 3e-5 relative (the exact fp32 chain of the same launch: <= 2e-6),
+    i.e. two orders inside the 1e-3 gate it exists for; ragged M / N / K edges and the epilogues behave like the exact kernel."""
+    from seedstory import _lib
+    a = synth.normal_like(14, (M, K), 1.0)
+    w = synth.normal_like(15, (N, K), 0.05)
+    bias = synth.normal_like(16, (N,), 0.5)
+    res = synth.normal_like(17, (M, N), 1.0)
+    ref = (a.double() @ w.double().t())
+    exact = ops.gemm(dev(a), dev(w))
+    _lib.set_tuning("gemm_f32_split", 1)
+    try:
+        y = ops.gemm(dev(a), dev(w))
+        yb = ops.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res))
+        yg = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True)
+    finally:
+        _lib.set_tuning("gemm_f32_split", 0)
+    e_split, e_exact = rel(y.double().cpu(), ref), rel(exact.double().cpu(), ref)
+    print("gemm [%d, %d, %d] fp32: split-bf16 %.2e vs exact-fp32 %.2e from the fp64 product" % (M, N, K, e_split, e_exact))
+    assert e_exact < 2e-6 and e_split < 3e-5 and not torch.equal(y, exact)
+    assert rel(yb.double().cpu(), ref + bias.double() + res.double()) < 3e-5
+    assert rel(yg.double().cpu(), torch.nn.functional.gelu(ref + bias.double())) < 5e-5
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3])
 def test_gemm_every_tile_config(ops, cfg):
     from seedstory import _lib
@@ -485,3 +511,31 @@ def test_gemm_splitk_small_m_weight_streaming(M, N, K, res, bias, dtype):
         assert nb == 0                                      # enough 128x128 workgroups without splitting
     y0 = ops.gemm(a, w, bias=b, residual=r)
     assert rel(y, y0) < tol
+
+
+@pytest.mark.parametrize("B,heads,hd,Lq,Lk,causal", [(16, 10, 64, 4096, 4096, False), (16, 20, 64, 1024, 1024, False), (16, 20, 64, 1024, 64, False),
+                                                    (3, 5, 64, 1000, 1000, False), (2, 3, 64, 130, 77, False), (1, 4, 64, 64, 64, False),
+                                                    (2, 4, 64, 333, 333, True), (1, 8, 64, 200, 913, True), (1, 2, 64, 33, 4096, True),
+                                                    (2, 4, 32, 300, 300, True), (3, 2, 40, 257, 100, False), (1, 6, 16, 64, 500, True)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_flash_v3p_equals_v3(B, heads, hd, Lq, Lk, causal, dtype):
+    """The shipped head-dim <= 64 kernel (attn_ver 6 = v3p: v3 with loop-invariant DMA source addresses, csrc/ss_attn.hip (1d))
+    performs the same arithmetic per score as v3, so the two must agree bit for bit on every shape class: self-attention with many
+    tiles, cross-attention with one tile, ragged tails in q and kv, bottom-right causal, head dims below 64 (toy models)."""
+    from seedstory import _lib, ops
+    E = heads * hd
+    g = torch.Generator(device=DEV).manual_seed(Lq * 7 + Lk + heads + hd)
+    q = torch.randn(B, Lq, E, device=DEV, dtype=dtype, generator=g)
+    k = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    v = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    k[:, Lk // 3] *= 6.0                     # a dominant key mid-stream: the deferred-rescale branch
+    outs = {}
+    for vv in (3, 6):
+        _lib.set_tuning("attn_ver", vv)
+        try:
+            outs[vv] = ops.attention(q, k, v, heads, None, causal).clone()
+        finally:
+            _lib.set_tuning("attn_ver", 6)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[6].float()).all())
+    assert torch.equal(outs[3], outs[6]), float((outs[3].float() - outs[6].float()).abs().max())

@@ -14,7 +14,10 @@ colsum = wg.float().sum(1).contiguous()
 rstd, shift = ops.rowstats(y, 1e-5)
 yf = y.float()
 zref = (rstd[:,None]*(yf @ wg.float().t()) + shift[:,None]*colsum[None,:])
-for cfg in (0, 61, 62, 65, 67, 60):
+W4 = int(os.environ.get("LNFOLD_W4", "1"))      # 1: offer the 4-wave folded tiles again (the re-check ADVICE r4 asks for)
+_lib.set_tuning("lnfold_w4", W4)
+print("lnfold_w4 =", W4)
+for cfg in (0, 61, 62, 65, 67, 68, 70, 60):
     _lib.set_tuning("gemm_cfg", cfg)
     tot = 0
     for it in range(4):
@@ -22,6 +25,24 @@ for cfg in (0, 61, 62, 65, 67, 60):
         ee = ((z0.float()-zref).norm(dim=1)/(zref.norm(dim=1)+1e-30))
         tot += int((ee > 1e-2).sum())
     print("cfg", cfg, "bad rows over 4 runs:", tot, "rel", rel(z0, zref))
+_lib.set_tuning("gemm_cfg", 0)
+_lib.set_tuning("lnfold_w4", 0)
+# the rowpart PRODUCER epilogue on the 4-wave tiles (ids 261 / 265 / 267): per-strip (sum, sum of squares) vs a host reduction
+for cfg in (61, 65, 67, 62):
+    _lib.set_tuning("gemm_cfg", cfg)
+    strips = ops.rowpart_strips(M, Nc, K, BF)
+    if strips <= 0:
+        print("rowpart cfg", cfg, "not eligible"); continue
+    bad = badv = 0
+    ref = (yf @ wg.float().t())
+    for it in range(4):
+        part = torch.full((M, strips, 2), float("nan"), device=DEV)
+        z = ops.gemm(y, wg, rowpart=part)
+        zf = z.float()
+        s1, s2 = part[:, :, 0].sum(1), part[:, :, 1].sum(1)
+        bad += int(((s1 - zf.sum(1)).abs() > 1e-3 * zf.abs().sum(1)).sum()) + int(((s2 - (zf * zf).sum(1)).abs() > 1e-3 * (zf * zf).sum(1)).sum())
+        badv += int((((zf - ref).norm(dim=1)) / (ref.norm(dim=1) + 1e-30) > 1e-2).sum())
+    print("rowpart producer cfg", cfg, "strips", strips, "bad statistics rows over 4 runs:", bad, "bad value rows:", badv)
 _lib.set_tuning("gemm_cfg", 0)
 for cfg in (61,):
     _lib.set_tuning("gemm_cfg", cfg)

@@ -120,7 +120,7 @@ def cmd_attn():
             tag = "v%d%s" % (ver, "x" if xcd else "")
             row[tag + "_us"] = round(us, 1)
             row[tag + "_tflops"] = round(flops / (us * 1e-6) / 1e12, 1)
-        _lib.set_tuning("attn_ver", 3)
+        _lib.set_tuning("attn_ver", 6)
         _lib.set_tuning("attn_xcd", 1)
         res.append(row)
         print(row)
