@@ -217,6 +217,57 @@ def llama7b_truth():
                                 note="LLaMA-2-7B 32 layers: prefill 64 + 66-row continuation + 3 decode tokens, fp32 and bf16 oracle runs")
     return ({k: R["f32." + k] for k in _L7_KEYS}, {k: R["bf16." + k] for k in _L7_KEYS}, how)
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_sink_continuation_full_width(dtype):
+    """The multimodal attention sink (vis_george_sink.py:243-295 as intended; seedstory/story.py) at LLaMA-7B WIDTH — hidden 4096,
+    32 heads of 128, inter 11008, 2 layers: three images in context, window 1, so TWO evictions on the KV slab (the first keeps the
+    4 start positions, the second extends the existing sink prefix), each followed by a continuation with window-relative query
+    positions against keys that keep their original rotary phase.  Hidden rows and the re-packed K plane vs the oracle run on the
+    gathered cache.  The tiny-model version is tests/test_engine_gpu.py::test_attention_sink_continuation_matches_oracle; the
+    bench drives the same calls with --sink."""
+    from seedstory.llama import LlamaEngine
+    from seedstory.story import StoryContext
+    w32 = _llama_weights()
+    wd = {k: v.to(dtype) for k, v in w32.items()}
+    dims = O.LlamaDims(H, NH, NL, INTER, VOCAB)
+    emb = wd["model.embed_tokens.weight"]
+    eng = LlamaEngine(wd, hidden=H, n_heads=NH, n_layers=NL, inter=INTER, vocab=VOCAB, dtype=dtype, device=DEV,
+                      cache_cap=512, max_new=16, max_prefill_rows=256, img_ids=IMG_IDS)
+    tol = 1e-4 if dtype == torch.float32 else 2.5e-2
+    ctx = StoryContext(bos_id=1, boi_id=IMG_IDS[0], eoi_id=IMG_IDS[-1], img_placeholder_ids=IMG_IDS[1:-1], window=1)
+    ctx.start(synth.randint(70, (9,), 3, 32000).tolist(), torch.zeros(1, 4, 8))
+    ctx.append_step(synth.randint(71, (7,), 3, 32000).tolist(), torch.zeros(1, 4, 8))
+    ids = torch.tensor(ctx.ids)
+    S = len(ctx.ids)                                              # 1 + 9 + 66 + 7 + 66 = 149
+    eng.reset()
+    eng.prefill(emb[ids])
+    _, _, kv = O.llama_forward(wd, dims, emb[ids][None], torch.arange(S)[None], None, all_logits=False)
+    kv_len = S
+    for round_no in range(2):
+        b = ctx.ids.index(IMG_IDS[0]) + ctx.sink_len
+        e = ctx.ids.index(IMG_IDS[-1]) + ctx.sink_len
+        keep, new_sink = O.sink_evict_indices(kv_len, b, e, ctx.sink_len, ctx.sink_len == 0)
+        kv_len = ctx.evict_sink(eng, kv_len)
+        assert kv_len == len(keep) == eng.lengths()[0] and ctx.sink_len == new_sink == (28 if round_no == 0 else 52)
+        kv = [(k[:, :, keep], v[:, :, keep]) for k, v in kv]
+        assert rel(eng.k_cache[0, :, :kv_len], kv[0][0][0]) < tol and rel(eng.v_cache[1, :, :kv_len], kv[1][1][0]) < tol
+        window_len = len(ctx.ids)
+        eng.set_lengths(kv_len, window_len)                       # new queries: window-relative positions
+        # the next pair: caption + an image block (its rows play the spliced features), appended to the window
+        new_ids = synth.randint(72 + round_no, (6,), 3, 32000).tolist() + IMG_IDS
+        hid = eng.prefill(emb[torch.tensor(new_ids)], want_hidden=True)
+        pos = torch.arange(window_len, window_len + len(new_ids))[None]
+        _, ref_hid, kv = O.llama_forward(wd, dims, emb[torch.tensor(new_ids)][None], pos, kv, all_logits=False)
+        r = rel(hid, ref_hid[0])
+        print("sink continuation full width %s, eviction %d: kv %d (sink %d), hidden rel %.2e" % (
+            str(dtype).split(".")[-1], round_no + 1, kv_len, ctx.sink_len, r))
+        assert r < tol
+        ctx.ids = ctx.ids + new_ids
+        ctx.image_embeds = torch.zeros(ctx.image_embeds.shape[0] + 1, 4, 8)
+        kv_len += len(new_ids)
+        assert eng.lengths() == (kv_len, window_len + len(new_ids))
+
+
 
 def test_llama_7b_all_32_layers():
     """The WHOLE LLaMA-2-7B configuration (4096 / 32 heads / 32 layers / 11008 / 32066: 6.74 B parameters) — the depth the

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 5, second GPU call: the new kernels / modes of this round.   tools/gpu_round5b.sh <stage>
+#   tests   new + touched tests (split-bf16 gate mode, v3p default, sink at full width, position-table bound, dtype policy)
+#   lnfold  tools/dbg_lnfold_vec.py with the 4-wave folded tiles offered again + the rowpart producers
+#   sink    bench --sink --story-len 25 (BASELINE configs[4] as named), bf16 and --unet-fp8, one whole story each
+#   gate    bench defaults without cpu baseline / batch1: tolerance_modes.gate_mode (full pipeline with the split-bf16 MLLM half)
+cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+export TMPDIR=/tmp
+case "$1" in
+tests)
+  timeout 1200 python -m pytest -q -x tests/test_kernels_gpu.py tests/test_errors_gpu.py "tests/test_frontend_full_gpu.py" \
+     "tests/test_fulldim_gpu.py::test_attention_sink_continuation_full_width" "tests/test_fulldim_gpu.py::test_sdxl_attention_shapes_bf16" \
+     tests/test_engine_gpu.py -s --durations=10 > gpurun_out/r5b_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r5b_tests.log
+  grep -E "split-bf16|img_gen_feat|sink continuation|passed|failed|rc=|Error|error" gpurun_out/r5b_tests.log | tail -60;;
+lnfold)
+  timeout 300 python tools/dbg_lnfold_vec.py > gpurun_out/r5b_lnfold.log 2>&1; echo "rc=$?" >> gpurun_out/r5b_lnfold.log; cat gpurun_out/r5b_lnfold.log | tail -30;;
+sink)
+  for tag in "bf16" "fp8:--unet-fp8"; do
+    name=${tag%%:*}; extra=""; [ "$tag" != "$name" ] && extra=${tag#*:}
+    timeout 600 python bench.py --sink --story-len 25 --steps 25 --warmup 0 --no-cpu-baseline --no-batch1 --no-tolerance-modes $extra > gpurun_out/r5b_sink_$name.log 2>&1
+    echo "rc=$?"; grep '^{"metric' gpurun_out/r5b_sink_$name.log | tail -1 > gpurun_out/r5b_sink_$name.json
+    python -c "import json;d=json.load(open('gpurun_out/r5b_sink_$name.json'));print('$name', d['value'], d['ms_per_step'], d['config']['attention_sink'])" || tail -20 gpurun_out/r5b_sink_$name.log
+  done
+  timeout 600 python bench.py --story-len 25 --steps 25 --warmup 0 --no-cpu-baseline --no-batch1 --no-tolerance-modes --no-roofline > gpurun_out/r5b_len25_reprefill.log 2>&1
+  grep '^{"metric' gpurun_out/r5b_len25_reprefill.log | tail -1 > gpurun_out/r5b_len25_reprefill.json
+  python -c "import json;d=json.load(open('gpurun_out/r5b_len25_reprefill.json'));print('len25 re-prefill', d['value'], d['ms_per_step'])";;
+gate)
+  timeout 900 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 > gpurun_out/r5b_gate.log 2>&1; echo "rc=$?"
+  grep '^{"metric' gpurun_out/r5b_gate.log | tail -1 > gpurun_out/r5b_gate.json
+  python -c "import json;d=json.load(open('gpurun_out/r5b_gate.json'));print(d['value'], d['ms_per_step']);print(json.dumps(d['tolerance_modes'],indent=1)[:3000]);print(json.dumps(d['roofline'].get('gemm_8192cubed_control')))" || tail -30 gpurun_out/r5b_gate.log;;
+*) echo "unknown stage $1"; exit 2;;
+esac
