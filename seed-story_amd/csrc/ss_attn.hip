@@ -1024,6 +1024,202 @@ void flash_attn3p_kernel(const AttnArgs a) {
     }
 }
 
+#if SS_EXPERIMENTAL
+// --------------------------------------------------------------------------------------------
+// (1e) cross-attention against a SHORT context (round 5): head_dim 64, kv_len <= 64 — the UNet's attn2 (64 image-feature
+//   tokens): 120 launches per forward.  Through the flash kernels such a launch is one K/V tile per workgroup: DMA the tile,
+//   wait, S, softmax, PV, store — a chain of latencies with nothing to overlap, 70.9 us for 84 MB of Q-in / O-out = 1.2 TB/s
+//   (profiles/round4_unet_batch16_kernel_trace.txt: 8.5 ms per batch-16 forward for 0.65 TFLOP).  The whole context of a
+//   (batch, head) pair is 8 KB of K and 8 KB of V, so here it lives in REGISTERS as ready MFMA fragments (K: 8 x 16 B as the
+//   first operand of S^T = K Q^T; V^T: 8 x 16 B in the key order the P fragments come out in) and a workgroup STREAMS query
+//   rows through it: a persistent grid of 2 workgroups per CU, each walking a contiguous range of (pair, 128-row chunk) work
+//   items — the fragments are reloaded only when the pair changes — with the next item's Q rows requested before the current
+//   item is computed.  HBM-bound by design: Q in, O out, nothing else.
+//   Arithmetic per score identical to flash v3 / v3p with a single tile (same MFMA order in S and PV, true row maximum,
+//   exp2 in the log2 domain, P rounded to the tensor dtype, row sums of the ROUNDED P by the ones-MFMA), so results are
+//   bit-equal to those kernels (tests/test_kernels_gpu.py::test_cross_attention_kv64_equals_flash) and the fp32-oracle
+//   tolerances carry over.
+//   MEASURED ON MI355X AND NOT ADOPTED (profiles/round5_cross_attn_b16.json): the premise was a misreading of the kernel trace —
+//   the 70.9 us average there mixes 60 self-attention launches (116 us) with 60 cross-attention launches, which the flash path
+//   already runs at 26.3 us = 3.2 TB/s (1024 tokens x 20 heads, batch 16) and 43.1 us = 3.9 TB/s (4096 x 10).  This kernel is
+//   bit-equal to it (42 equality cases passed) but SLOWER: 33.7 / 46.8 us — 8 waves per CU with one 4 KB query tile in flight
+//   each do not cover the HBM latency the way 12 resident flash workgroups do.  Kept only in the EXPERIMENTAL=1 build
+//   (tuning knob attn_cross64 = 1 selects it there; tests/test_experimental_gpu.py).
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void cross_attn64_kernel(const AttnArgs a, int n_items, int items_per_block, int chunks_per_pair) {
+    constexpr int HD = 64, NDB = 4, NKB = 4, NKS = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, grp = lane >> 4;
+    const float sl2 = a.scale * 1.4426950408889634f;
+    const uint4 ones = make_uint4(OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair, OnesFrag<T>::kPair);
+    const int kvl = a.kv_len;
+    const bool o_vec = ((a.o_ss | a.o_sh | a.o_sb) & 3) == 0;
+    int it = blockIdx.x * items_per_block;
+    int it_end = it + items_per_block;
+    if (it_end > n_items) it_end = n_items;
+    if (it >= it_end) return;
+
+    uint4 kf[NKB][NKS];      // K[key = kb*16 + l15][d = ks*32 + grp*8 ..]
+    uint4 vf[NKB / 2][NDB];  // V[key in the P-fragment order of (kp2, grp)][d = db*16 + l15], 8 keys per lane
+    int cur_pair = -1;
+    auto load_q = [&](int item, uint4 (&qf)[2][NKS]) {
+        const int pair = item / chunks_per_pair, chunk = item - pair * chunks_per_pair;
+        const int b = pair / a.n_heads, h = pair - b * a.n_heads;
+        const T* __restrict__ qp = (const T*)a.q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qi = chunk * 128 + wid * 32 + qb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                qf[qb][ks] = qi < a.q_len ? ld16(qp + (int64_t)qi * a.q_ss + ks * 32 + grp * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 qf[2][NKS], qn[2][NKS];
+    load_q(it, qf);
+    for (; it < it_end; ++it) {
+        const bool more = it + 1 < it_end;           // workgroup-uniform
+        if (more) load_q(it + 1, qn);                // in flight under this item's work
+        const int pair = it / chunks_per_pair, chunk = it - pair * chunks_per_pair;
+        const int b = pair / a.n_heads, h = pair - b * a.n_heads;
+        if (pair != cur_pair) {                      // (workgroup-uniform) the context of a new (batch, head) pair
+            cur_pair = pair;
+            const T* __restrict__ kp = (const T*)a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+            const T* __restrict__ vp = (const T*)a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int key = kb * 16 + l15;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    kf[kb][ks] = key < kvl ? ld16(kp + (int64_t)key * a.k_ss + ks * 32 + grp * 8) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const int k0 = (2 * kp2 + (j >> 2)) * 16 + grp * 4 + (j & 3), k1 = k0 + 1;
+                        const uint32_t lo = k0 < kvl ? (uint32_t)(vp + (int64_t)k0 * a.v_ss + db * 16 + l15)->v : 0u;
+                        const uint32_t hi = k1 < kvl ? (uint32_t)(vp + (int64_t)k1 * a.v_ss + db * 16 + l15)->v : 0u;
+                        w[j >> 1] = lo | (hi << 16);
+                    }
+                    vf[kp2][db] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+        }
+        // ---- S^T = K Q^T ------------------------------------------------------------------------------
+        f32x4_t s[2][NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            s[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            s[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                s[0][kb] = AttnMma<T>::run(kf[kb][ks], qf[0][ks], s[0][kb]);
+                s[1][kb] = AttnMma<T>::run(kf[kb][ks], qf[1][ks], s[1][kb]);
+            }
+        }
+        // ---- softmax numerators: true row maximum (the four lane groups of a row), exp2 in the log2 domain ---------------
+        uint4 pfrag[2][NKB / 2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (kvl < 64) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * 16 + grp * 4 + r >= kvl) s[qb][kb][r] = -1e30f;
+            }
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float nm = -fmaxf(tmax, -1e29f) * sl2;
+#pragma unroll
+            for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+                float pf[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2][r], sl2, nm));
+                    pf[4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qb][2 * kp2 + 1][r], sl2, nm));
+                }
+                pfrag[qb][kp2] = pack<T>(pf);
+            }
+        }
+        // ---- O^T = V^T P^T, l = 1^T P^T ---------------------------------------------------------------------------------
+        f32x4_t o[2][NDB], osum[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            osum[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) o[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kp2 = 0; kp2 < NKB / 2; ++kp2) {
+            osum[0] = AttnMma<T>::run(ones, pfrag[0][kp2], osum[0]);
+            osum[1] = AttnMma<T>::run(ones, pfrag[1][kp2], osum[1]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                o[0][db] = AttnMma<T>::run(vf[kp2][db], pfrag[0][kp2], o[0][db]);
+                o[1][db] = AttnMma<T>::run(vf[kp2][db], pfrag[1][kp2], o[1][db]);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qi = chunk * 128 + wid * 32 + qb * 16 + l15;
+            if (qi >= a.q_len) continue;
+            const float l = osum[qb][0];
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* op = (T*)a.out + (int64_t)b * a.o_sb + (int64_t)h * a.o_sh + (int64_t)qi * a.o_ss;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int d = db * 16 + grp * 4;
+                if (o_vec) {
+                    float pk[8] = {o[qb][db][0] * inv, o[qb][db][1] * inv, o[qb][db][2] * inv, o[qb][db][3] * inv, 0, 0, 0, 0};
+                    const uint4 u = pack<T>(pk);
+                    *reinterpret_cast<uint2*>(op + d) = make_uint2(u.x, u.y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tr<T>::st(op + d + r, o[qb][db][r] * inv);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = qn[qb][ks];
+        }
+    }
+}
+
+template <typename T>
+static int cross_attn64_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
+    const int cpp = cdiv(a.q_len, 128);
+    const int64_t n_items = batch * a.n_heads * cpp;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t max_blocks = (int64_t)2 * n_cu;                 // 2 workgroups (8 waves) per CU: the kernel's occupancy
+    const int ipb = (int)((n_items + max_blocks - 1) / max_blocks);
+    const int grid = (int)((n_items + ipb - 1) / ipb);
+    hipLaunchKernelGGL((cross_attn64_kernel<T>), dim3((unsigned)grid), dim3(256), 0, s, a, (int)n_items, ipb, cpp);
+    SS_LAUNCH_CHECK("cross_attn64");
+    return SS_OK;
+}
+
+#endif  // SS_EXPERIMENTAL (cross_attn64)
+
 template <typename T, bool PIPE>
 static int flash3p_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     const size_t lds = (size_t)3 * 2 * kBKV * 64 * 2;   // ring of 3 (K, V) tiles
@@ -1097,6 +1293,11 @@ int attention_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
         // v3 for head_dim 128; 3 = v3 with the swizzled V image everywhere, 4 = v3 with the linear V image,
         // 5 = v3p WITH the prefetch (measured slower than v3: 2 waves per SIMD)
         const int ver = tuning_get("attn_ver", 6);
+#if SS_EXPERIMENTAL
+        // option (1e): a short context (the UNet's cross-attention over 64 image-feature tokens) with K / V held in registers
+        if (a.hd == 64 && a.kv_len <= 64 && !a.causal_br && !a.ragged && a.q_len >= 128 && ver >= 3 && tuning_get("attn_cross64", 0))
+            return cross_attn64_launch<T>(a, batch, s);
+#endif
         if (ver == 5 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, true>(a, batch, s);     // options: v3p (see (1d))
         if (ver == 6 && a.q_len >= 32 && a.hd <= 64) return flash3p_launch<T, false>(a, batch, s);
         if (ver >= 3 && a.q_len >= 32) {

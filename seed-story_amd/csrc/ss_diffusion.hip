@@ -55,6 +55,18 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
         if (active) {
             const T* xp = xb + (int64_t)p * V;
             int r = r0 + ry;
+            for (; r + 3 * rip < r1; r += 4 * rip) {       // four independent loads in flight (round 5: 2.0 -> HBM rate; same add order)
+                uint4 u[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[q] = ld16(xp + (int64_t)(r + q * rip) * C);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float f[V];
+                    unpack<T>(u[q], f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+                }
+            }
             for (; r + rip < r1; r += 2 * rip) {           // two independent loads in flight
                 float f[V], h[V];
                 const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
@@ -177,6 +189,13 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
             st16(yp + (int64_t)r * C, pack<T>(f));
         };
         int r = r0 + ry;
+        for (; r + 3 * rip < r1; r += 4 * rip) {           // four rows in flight per thread
+            uint4 u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = ld16(xp + (int64_t)(r + q * rip) * C);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) one(u[q], r + q * rip);
+        }
         for (; r + rip < r1; r += 2 * rip) {
             const uint4 u0 = ld16(xp + (int64_t)r * C), u1 = ld16(xp + (int64_t)(r + rip) * C);
             one(u0, r);

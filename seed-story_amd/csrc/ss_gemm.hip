@@ -786,13 +786,13 @@ int gemm_lnfold_launch(const void* A, const void* Wg, void* C, int64_t M, int64_
         g.ln_part = ln_part; g.ln_nstrip = (int)ln_nstrip; g.ln_inv_width = ln_width > 0 ? 1.0f / (float)ln_width : 0.f; g.ln_eps = ln_eps;
         int cfg = lookup_cfg<T>(g);
         if (cfg < 60 || cfg > 72) cfg = N % 160 == 0 ? (M >= 2048 ? 62 : 61) : (M * N >= 128 * 128 * 256 ? 65 : 70);
-        // Round 4: the folded epilogue runs on the 8-wave tiles only.  On the 4-wave tiles (61 / 65 / 67 / 68 / 70: two
-        // workgroups per CU) it sporadically returned ONE wrong element per 16-row strip of the last fragment column of a wave
-        // (tools/dbg_lnfold_vec.py: 16-128 bad rows per 4 launches at [32768, 640, 640]; the plain epilogue on the same tiles and
-        // the folded one on the 8-wave tiles: none in the same runs).  The accumulator fences behind the K loop
-        // (ss_gemm_sp.inc, "MFMA results settle before VALU reads them") were added afterwards for exactly this signature; the
-        // reroute stays until tools/dbg_lnfold_vec.py has re-checked the 4-wave tiles WITH the fences (`lnfold_w4` = 1 offers
-        // them again for that check; status of the re-check: DESIGN §4, LayerNorm-fold row).
+        // The folded epilogue runs on the 8-wave tiles only.  On the 4-wave tiles (61 / 65 / 67 / 70: two workgroups per CU) it
+        // sporadically returns ONE wrong element per 16-row strip of the last fragment column of a wave.  Round 5 re-ran
+        // tools/dbg_lnfold_vec.py WITH the accumulator fences behind the K loop (ss_gemm_sp.inc, "MFMA results settle before
+        // VALU reads them") and `lnfold_w4` = 1 (profiles/round5_lnfold_w4_recheck.txt): still 80 / 96 / 96 / 304 bad rows per
+        // 4 launches at [32768, 640, 640] on cfg 61 / 65 / 67 / 70, none on 62 / 68 / 60 — the fences do NOT fix it, the cause is
+        // still open, the reroute stays.  The same run cleared the PRODUCER side: the rowpart statistics epilogue on the 4-wave
+        // tiles 261 / 265 / 267 (and 262) gave 0 bad statistics rows and 0 bad value rows, and the plain epilogue on cfg 61 none.
         if (!tuning_get("lnfold_w4", 0)) {
             if (cfg == 61 || cfg == 67) cfg = 62;
             else if (cfg == 65 || cfg == 68 || cfg == 70) cfg = N % 160 == 0 ? 62 : 66;

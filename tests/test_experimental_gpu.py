@@ -52,3 +52,41 @@ def test_flash_v3p_head_dim_128_falls_back_to_v3():
         finally:
             _lib.set_tuning("attn_ver", 6)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk", [(16, 20, 1024, 64), (16, 10, 4096, 64), (2, 20, 1024, 64), (2, 10, 4096, 64), (3, 5, 1000, 64),
+                                          (2, 4, 333, 50), (1, 2, 128, 1), (5, 3, 129, 17), (1, 40, 2048, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cross_attention_kv64_equals_flash(B, heads, Lq, Lk, dtype):
+    """Short-context cross-attention (head_dim 64, kv_len <= 64: the UNet's attn2) through the register-resident streaming kernel
+    (csrc/ss_attn.hip (1e); EXPERIMENTAL=1 build only, attn_cross64 = 1) must EQUAL the flash path bit for bit — same arithmetic
+    per score — and sit inside the flash kernels' tolerance of the fp32 softmax attention.  Covers the persistent walk over several
+    (batch, head) pairs per workgroup, ragged query tails, contexts shorter than 64 keys, and a context of ONE key.  Round 5 ran
+    these on MI355X (all equal) and measured the kernel slower than the flash path, so it is not in the default build."""
+    from seedstory import _lib, ops
+    E = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(Lq * 3 + Lk + heads)
+    q = torch.randn(B, Lq, E, device=DEV, dtype=dtype, generator=g)
+    k = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    v = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    k[:, Lk // 3] *= 6.0
+    y_flash = ops.attention(q, k, v, heads).clone()
+    _lib.set_tuning("attn_cross64", 1)
+    try:
+        y = ops.attention(q, k, v, heads).clone()
+    finally:
+        _lib.set_tuning("attn_cross64", 0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y.float()).all())
+    assert torch.equal(y, y_flash), float((y.float() - y_flash.float()).abs().max())
+    b = B - 1
+    qh = q[b].float().view(Lq, heads, 64).transpose(0, 1)
+    kh = k[b].float().view(Lk, heads, 64).transpose(0, 1)
+    vh = v[b].float().view(Lk, heads, 64).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) / 8.0, dim=-1) @ vh).transpose(0, 1).reshape(Lq, E)
+    assert rel(y[b], ref) < 6e-3

@@ -28,5 +28,16 @@ gate)
   timeout 900 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 > gpurun_out/r5b_gate.log 2>&1; echo "rc=$?"
   grep '^{"metric' gpurun_out/r5b_gate.log | tail -1 > gpurun_out/r5b_gate.json
   python -c "import json;d=json.load(open('gpurun_out/r5b_gate.json'));print(d['value'], d['ms_per_step']);print(json.dumps(d['tolerance_modes'],indent=1)[:3000]);print(json.dumps(d['roofline'].get('gemm_8192cubed_control')))" || tail -30 gpurun_out/r5b_gate.log;;
+cross)
+  # the register-resident cross-attention kernel + the 4-deep GroupNorm loops: equality / oracle tests, then timings
+  timeout 900 python -m pytest -q -x tests/test_kernels_gpu.py -k "cross_attention or v3p" "tests/test_fulldim_gpu.py::test_sdxl_attention_shapes_bf16" \
+     tests/test_sdxl_gpu.py "tests/test_fulldim_gpu.py::test_sdxl_transformer_block_full_size" "tests/test_fulldim_gpu.py::test_sdxl_resblock_full_size" \
+     "tests/test_fulldim_gpu.py::test_sdxl_unet_assembled_full_size_bf16" > gpurun_out/r5b_cross_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r5b_cross_tests.log
+  tail -6 gpurun_out/r5b_cross_tests.log
+  timeout 200 python tools/kbench.py cross --batch 16 > gpurun_out/r5b_cross_kbench.log 2>&1; tail -3 gpurun_out/r5b_cross_kbench.log
+  cp gpurun_out/cross_attn.json gpurun_out/r5b_cross_attn_b16.json 2>/dev/null
+  for k in "attn_cross64=1" "attn_cross64=0"; do
+    KB_KNOBS=$k timeout 300 python tools/kbench.py unet --batch 16 2>&1 | tail -1 | sed "s/^/$k /"
+  done | tee gpurun_out/r5b_unet_ab.log;;
 *) echo "unknown stage $1"; exit 2;;
 esac

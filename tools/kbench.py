@@ -138,8 +138,12 @@ def cmd_cross(UB=8):
         kv = torch.randn(UB * 64, 2 * E, device=DEV, dtype=dt)
         qkv = torch.randn(UB * L, 3 * E, device=DEV, dtype=dt)
         us_c = min(timed(lambda: ops.attention_q_kvpacked(q, kv, UB, L, 64, heads), n=20) for _ in range(3))
+        _lib.set_tuning("attn_cross64", 0)          # the flash path the register-resident kernel replaced (round 5)
+        us_f = min(timed(lambda: ops.attention_q_kvpacked(q, kv, UB, L, 64, heads), n=20) for _ in range(3))
+        _lib.set_tuning("attn_cross64", 1)
         us_s = min(timed(lambda: ops.attention_qkv_packed(qkv, UB, L, heads), n=10) for _ in range(3))
         row = {"B": UB, "heads": heads, "L": L, "cross_us": round(us_c, 1), "cross_GBps": round(2 * q.numel() * 2 / us_c / 1e3, 1),
+               "cross_flash_us": round(us_f, 1), "cross_flash_GBps": round(2 * q.numel() * 2 / us_f / 1e3, 1),
                "self_us": round(us_s, 1), "self_tflops": round(4.0 * UB * heads * L * L * 64 / us_s / 1e6, 1)}
         print(row)
         res.append(row)
@@ -223,6 +227,9 @@ def cmd_vae():
 
 
 if __name__ == "__main__":
+    for kv in os.environ.get("KB_KNOBS", "").split(","):       # A/B runs: KB_KNOBS="attn_cross64=0,attn_ver=3"
+        if "=" in kv:
+            _lib.set_tuning(kv.split("=")[0].strip(), int(kv.split("=")[1]))
     cmd = sys.argv[1] if len(sys.argv) > 1 else "tune"
     batch = 8
     if "--batch" in sys.argv:
