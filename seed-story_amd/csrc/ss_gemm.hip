@@ -25,12 +25,15 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
 // way into LDS, x = hi + lo with hi = bf16(x) and lo = bf16(x - hi) (x - hi is exact in fp32), and the product is formed on the
 // bf16 matrix pipe as  A·W^T ~= Ahi·Whi^T + Ahi·Wlo^T + Alo·Whi^T  with fp32 accumulation — three v_mfma_f32_16x16x32_bf16 per
 // fragment pair and 32 k instead of eight v_mfma_f32_16x16x4_f32 at 1/16 of the rate.  The dropped Alo·Wlo term and the
-// 16-bit operand mantissas leave a relative error of ~2^-17 per product (random sign): ~1e-5 per GEMM against the exact fp32 FMA
-// chain, two orders inside the 1e-3 gate on the regressed image features.  Same tile, same LDS footprint (a row is 64 B of
-// hi + 64 B of lo + one 16-byte pad instead of 128 B of fp32 + pad), same loads, same epilogue.
+// 16-bit operand mantissas leave a relative error of ~2^-17 per product (random sign): measured 4.5e-6 per GEMM against the
+// fp64 product (exact fp32 chain: 1.4e-7 .. 1.6e-6), two orders inside the 1e-3 gate on the regressed image features.  Same
+// loads, same epilogue, same LDS bytes per row (BK/2 bf16 of hi, then BK/2 bf16 of lo, then the 16-byte pad — where the exact
+// mode keeps BK fp32 values).  Launched with 64-wide K tiles (KT = 2): with 32-wide tiles the three MFMAs per fragment pair are
+// done in ~770 cycles, less than the L2 round trip of the NEXT tile's register-staged loads, and the kernel ran only 1.25x
+// faster than the exact chain (round 5, first measurement: MLLM half 1100 vs 1283 ms per round).
 template <typename T, int BM, int BN, int WM, int WN, int KT, bool CONV, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
-    static_assert(!SPLIT || (Tr<T>::kVec == 4 && KT == 1), "SPLIT: fp32 operands, one 32-wide k tile");
+    static_assert(!SPLIT || Tr<T>::kVec == 4, "SPLIT: fp32 operands");
     constexpr int V = Tr<T>::kVec;
     constexpr int NT = 64 * WM * WN;     // threads per block
     constexpr int PPR = 8 * KT;          // packs per tile row
@@ -103,14 +106,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             rw[i] = (p < BN * PPR && n < N && k < K) ? ld16(W + (int64_t)n * g.ldw + k) : make_uint4(0, 0, 0, 0);
         }
     };
-    // SPLIT: pack c of a row (k = 4c .. 4c+3) -> 8 bytes of hi at byte 8c and 8 bytes of lo at byte 64 + 8c of the row
+    // SPLIT: pack c of a row (k = 4c .. 4c+3) -> 8 bytes of hi at byte 8c and 8 bytes of lo at byte 2*BK + 8c of the row
     auto split_store = [&](char* row, int c, const uint4& u) {
         const float x0 = __uint_as_float(u.x), x1 = __uint_as_float(u.y), x2 = __uint_as_float(u.z), x3 = __uint_as_float(u.w);
         const uint32_t h01 = f32x2_to_bf16x2_bits(x0, x1), h23 = f32x2_to_bf16x2_bits(x2, x3);
         const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
         const float r2 = x2 - __uint_as_float(h23 << 16), r3 = x3 - __uint_as_float(h23 & 0xffff0000u);
         *reinterpret_cast<uint2*>(row + c * 8) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(row + 64 + c * 8) = make_uint2(f32x2_to_bf16x2_bits(r0, r1), f32x2_to_bf16x2_bits(r2, r3));
+        *reinterpret_cast<uint2*>(row + 2 * BK + c * 8) = make_uint2(f32x2_to_bf16x2_bits(r0, r1), f32x2_to_bf16x2_bits(r2, r3));
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -137,27 +140,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
         if (t + 1 < ntiles) load_tile(t + 1);  // in flight while the MFMAs run
         if constexpr (SPLIT) {
-            uint4 fwh[FN], fwl[FN], fah[FM], fal[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const char* r = reinterpret_cast<const char*>(Ws + (wn * TN + i * 16 + l15) * LS) + grp * 16;
-                fwh[i] = *reinterpret_cast<const uint4*>(r);
-                fwl[i] = *reinterpret_cast<const uint4*>(r + 64);
-            }
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                uint4 fwh[FN], fwl[FN], fah[FM], fal[FM];
 #pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                const char* r = reinterpret_cast<const char*>(As + (wm * TM + j * 16 + l15) * LS) + grp * 16;
-                fah[j] = *reinterpret_cast<const uint4*>(r);
-                fal[j] = *reinterpret_cast<const uint4*>(r + 64);
-            }
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) {       // the two cross terms first, the leading term last
-                    acc[i][j] = Mma<bf16_t>::run(fwl[i], fah[j], acc[i][j]);
-                    acc[i][j] = Mma<bf16_t>::run(fwh[i], fal[j], acc[i][j]);
-                    acc[i][j] = Mma<bf16_t>::run(fwh[i], fah[j], acc[i][j]);
+                for (int i = 0; i < FN; ++i) {
+                    const char* r = reinterpret_cast<const char*>(Ws + (wn * TN + i * 16 + l15) * LS) + ks * 64 + grp * 16;
+                    fwh[i] = *reinterpret_cast<const uint4*>(r);
+                    fwl[i] = *reinterpret_cast<const uint4*>(r + 2 * BK);
                 }
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const char* r = reinterpret_cast<const char*>(As + (wm * TM + j * 16 + l15) * LS) + ks * 64 + grp * 16;
+                    fah[j] = *reinterpret_cast<const uint4*>(r);
+                    fal[j] = *reinterpret_cast<const uint4*>(r + 2 * BK);
+                }
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {       // the two cross terms first, the leading term last
+                        acc[i][j] = Mma<bf16_t>::run(fwl[i], fah[j], acc[i][j]);
+                        acc[i][j] = Mma<bf16_t>::run(fwh[i], fal[j], acc[i][j]);
+                        acc[i][j] = Mma<bf16_t>::run(fwh[i], fah[j], acc[i][j]);
+                    }
+            }
         } else if constexpr (V == 8) {
 #pragma unroll
             for (int ks = 0; ks < BK / 32; ++ks) {
@@ -245,10 +251,19 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
     dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
     if constexpr (V == 4 && KT == 1) {      // fp32 tensors: the split-bf16 "gate mode" instead of the exact fp32 FMA chain
         if (tuning_get("gemm_f32_split", 0)) {
-            if (g.conv_Cin > 0)
-                hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, KT, true, true>), grid, dim3(64 * WM * WN), lds, s, g);
-            else
-                hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, KT, false, true>), grid, dim3(64 * WM * WN), lds, s, g);
+            constexpr int SKT = 2;                                  // 64-wide K tiles (see the kernel's header comment)
+            constexpr int SLS = 8 * SKT * V + V;
+            const size_t slds = (size_t)(BM + BN) * SLS * sizeof(T);
+            auto kern = g.conv_Cin > 0 ? gemm_kernel<T, BM, BN, WM, WN, SKT, true, true> : gemm_kernel<T, BM, BN, WM, WN, SKT, false, true>;
+            if (slds > 64 * 1024) {
+                static bool attr_set[2] = {false, false};
+                const int which = g.conv_Cin > 0 ? 1 : 0;
+                if (!attr_set[which]) {
+                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+                    attr_set[which] = true;
+                }
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), slds, s, g);
             SS_LAUNCH_CHECK("gemm_split");
             return SS_OK;
         }

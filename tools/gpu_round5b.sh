@@ -39,5 +39,15 @@ cross)
   for k in "attn_cross64=1" "attn_cross64=0"; do
     KB_KNOBS=$k timeout 300 python tools/kbench.py unet --batch 16 2>&1 | tail -1 | sed "s/^/$k /"
   done | tee gpurun_out/r5b_unet_ab.log;;
+split)
+  timeout 300 python -m pytest -q -x tests/test_kernels_gpu.py -k "f32_split" "tests/test_frontend_full_gpu.py::test_gate_mode_generate_hidden4096_img_gen_feat" -s 2>&1 | grep -E "split-bf16|img_gen_feat|passed|failed" | tail -16
+  timeout 300 python tools/split_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5b_split_bench.log;;
+traces)
+  # per-kernel traces of the batch-16 UNet forward and of one VAE decode (tools/trace_summary.py)
+  R=$PWD; rm -rf /tmp/tr /tmp/trv
+  (cd /tmp && export SS_UNET_BATCH=16 && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $R/tools/unet_trace.py > $R/gpurun_out/r5b_unet_trace.log 2>&1)
+  python tools/trace_summary.py $(find /tmp/tr -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/r5b_unet_batch16_kernel_trace.txt 2>&1; head -14 gpurun_out/r5b_unet_batch16_kernel_trace.txt
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/trv -o t -- python $R/tools/vae_trace.py > $R/gpurun_out/r5b_vae_trace.log 2>&1)
+  python tools/trace_summary.py $(find /tmp/trv -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/r5b_vae_decode_kernel_trace.txt 2>&1; head -40 gpurun_out/r5b_vae_decode_kernel_trace.txt;;
 *) echo "unknown stage $1"; exit 2;;
 esac
