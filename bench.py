@@ -786,7 +786,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
                         % (shipped_cfg, ff1_rec.get("cfg_swz")))
         roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 2.5e15, 4), "traffic": ff1_traffic,
-                "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
+                "kernel": "SDXL UNet forward, all kernels (ss::gemm_sp_kernel<bf16,*> incl. implicit-GEMM conv3x3, ss::flash_attn3p_kernel<bf16,64>, norms); traffic = HBM bytes per launch of the dominant ff1 GEMM",
                 "traffic_note": traffic_note, "tile_table_sha16": table_sha,
                 "pmc_record_tile_table_sha16": pmcj.get("tile_table_sha16"),    # (the table the counters ran on; rows are matched per shape + tile)
                 "flops_per_forward": flops, "forward_ms": round(ms, 3), "unet_batch": UB,
@@ -834,24 +834,48 @@ def measure_tolerance_modes(runner, engs, shared, rin, rout, vit, adapter, SPG, 
             finally:
                 _lib.set_tuning("vae_fp32", 0)
         dev_ = (imgs[0] - imgs[1]).abs().float()
+        # the fp32-tensor decode with its convolutions / linears as split-bf16 MFMA products (gemm_f32_split): 4.5e-6 per product
         _lib.set_tuning("vae_fp32", 1)
+        _lib.set_tuning("gemm_f32_split", 1)
         try:
-            runner.sts = None
-            runner.warm(1)
+            vae.decode_nhwc(lat, prescale=sc)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            img, Hh, Ww = vae.decode_nhwc(lat, prescale=sc)
+            e1.record()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 2
-            runner.run(n)
-            torch.cuda.synchronize()
-            v32 = n * SPG / (time.perf_counter() - t0)
+            ms_split = e0.elapsed_time(e1)
+            dev_s = (ops.image_to_u8(img, Hh * Ww).view(Hh, Ww, 3).int() - imgs[1]).abs().float()
         finally:
             _lib.set_tuning("vae_fp32", 0)
-            runner.sts = None
-        out["vae_fp32"] = {"value_vae_fp32": round(v32, 4), "value_bf16_vae": value_bf16, "unit": "story-steps/s",
-                           "rounds_timed": n, "decode_ms_bf16": round(ms[0], 2), "decode_ms_fp32": round(ms[1], 2),
+            _lib.set_tuning("gemm_f32_split", 0)
+
+        def rate(knobs, n=2):
+            for k in knobs:
+                _lib.set_tuning(k, 1)
+            try:
+                runner.sts = None
+                runner.warm(1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                runner.run(n)
+                torch.cuda.synchronize()
+                return n * SPG / (time.perf_counter() - t0)
+            finally:
+                for k in knobs:
+                    _lib.set_tuning(k, 0)
+                runner.sts = None
+        n = 2
+        v32 = rate(("vae_fp32",))
+        v32s = rate(("vae_fp32", "gemm_f32_split"))
+        out["vae_fp32"] = {"value_vae_fp32": round(v32, 4), "value_vae_fp32_split": round(v32s, 4), "value_bf16_vae": value_bf16,
+                           "unit": "story-steps/s", "rounds_timed": n, "decode_ms_bf16": round(ms[0], 2), "decode_ms_fp32": round(ms[1], 2),
+                           "decode_ms_fp32_split": round(ms_split, 2),
                            "uint8_dev_bf16_vs_fp32_decode": {"mean": round(float(dev_.mean()), 3), "max": int(dev_.max()),
                                                              "weights": "synthetic (random) VAE, latents ~ 3 x N(0, 1) x scaling"},
-                           "note": "diffusers decodes the SDXL VAE in fp32 (force_upcast); `value` above uses the bf16 decoder"}
+                           "uint8_dev_fp32_split_vs_fp32_decode": {"mean": round(float(dev_s.mean()), 5), "max": int(dev_s.max())},
+                           "note": "diffusers decodes an fp16 SDXL VAE in fp32 (force_upcast) and a bf16 one in bf16; `value` above uses the bf16 "
+                                   "decoder; fp32_split = fp32 tensors with the convolutions as three bf16 MFMA products per fragment pair"}
     # the MLLM half alone, bf16 (the benched engines) and exact fp32 (a second set of modules with fp32 weights)
     def mllm_rate(engines, rin_, rout_, vit_, n=2):
         r = Runner(engines if len(engines) > 1 else engines[0], rin_, rout_, vit_, None, SPG, device, args, 555000)

@@ -863,14 +863,17 @@ def test_vae_decode_full_size_vs_oracle_whole_image():
     t_cpu = time.time() - t0
     sc = 1.0 / vae.config.scaling_factor
 
-    def run(fp32):
+    def run(fp32, split=False):
         _lib.set_tuning("vae_fp32", 1 if fp32 else 0)
+        _lib.set_tuning("gemm_f32_split", 1 if split else 0)
         try:
             img, Hh, Ww = vae.decode_nhwc(lat.to(DEV, torch.bfloat16), prescale=sc)
             return img.float().cpu().view(Hh, Ww, -1)[:, :, :3].permute(2, 0, 1)[None], ops.image_to_u8(img, Hh * Ww).view(Hh, Ww, 3).cpu()
         finally:
             _lib.set_tuning("vae_fp32", 0)
+            _lib.set_tuning("gemm_f32_split", 0)
     f32, u32 = run(True)
+    fsp, usp = run(True, split=True)       # fp32 tensors, convs / linears as split-bf16 MFMA products (the affordable fp32-class decode)
     fbf, ubf = run(False)
     ref_u8 = S.postprocess(ref)[0]
     e32, ebf = rel(f32, ref), rel(fbf, ref)
@@ -880,6 +883,11 @@ def test_vae_decode_full_size_vs_oracle_whole_image():
           "bf16 HIP rel %.3e, uint8 mean |dev| %.3f, max %d" % (t_cpu, e32, int(d32.max()), ebf, float(dbf.mean()), int(dbf.max())))
     assert ref.shape == (1, 3, 1024, 1024) and e32 < 1e-3 and int(d32.max()) <= 1
     assert ebf < 3e-2 and float(dbf.mean()) < 1.0
+    esp = rel(fsp, ref)
+    dsp = (usp.int() - ref_u8.int()).abs().float()
+    print("   split-bf16 fp32-tensor decode: rel %.3e, uint8 max dev %d, pixels off by one level %.4f %%" % (
+        esp, int(dsp.max()), 100.0 * float((dsp > 0).float().mean())))
+    assert esp < 1e-3 and int(dsp.max()) <= 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------

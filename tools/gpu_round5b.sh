@@ -49,5 +49,15 @@ traces)
   python tools/trace_summary.py $(find /tmp/tr -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/r5b_unet_batch16_kernel_trace.txt 2>&1; head -14 gpurun_out/r5b_unet_batch16_kernel_trace.txt
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/trv -o t -- python $R/tools/vae_trace.py > $R/gpurun_out/r5b_vae_trace.log 2>&1)
   python tools/trace_summary.py $(find /tmp/trv -name "*kernel_trace.csv" | head -1) 3 > gpurun_out/r5b_vae_decode_kernel_trace.txt 2>&1; head -40 gpurun_out/r5b_vae_decode_kernel_trace.txt;;
+final)
+  # the round's records: smoke(), the default bench line (every leg), rocprofv3 --kernel-trace --stats of the bench command
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2
+  timeout 900 python bench.py > gpurun_out/r5_bench.log 2>&1; echo "bench rc=$?"; grep '^{"metric' gpurun_out/r5_bench.log | tail -1 > gpurun_out/r5_bench.json
+  python -c "import json;d=json.load(open('gpurun_out/r5_bench.json'));r=d['roofline'];print(d['value'],d['ms_per_step'],d['batch1'],r['forward_ms'],r['frac'],r['dominant_kernel']['avg_launch_us'],r['dominant_kernel']['frac'],r['mllm_decode_gemv']['avg_launch_us'],r['mllm_decode_gemv']['frac']);print(json.dumps(d['tolerance_modes'].get('gate_mode')));print(json.dumps(r.get('gemm_8192cubed_control')));print(d['cpu_baseline'])" || tail -30 gpurun_out/r5_bench.log
+  rm -rf gpurun_out/r5; mkdir -p gpurun_out/r5
+  B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --no-tolerance-modes --no-roofline"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/stats_overlap -o b -- $B > gpurun_out/r5_overlap.log 2>&1; echo "prof rc=$?"
+  find gpurun_out/r5 -name "*kernel_trace.csv" -delete
+  f=$(find gpurun_out/r5 -name "*kernel_stats.csv" | head -1); head -12 "$f" | cut -c1-200; cp "$f" gpurun_out/r5_bench_kernel_stats.csv; grep '^{"metric' gpurun_out/r5_overlap.log | tail -1 | cut -c1-120;;
 *) echo "unknown stage $1"; exit 2;;
 esac
