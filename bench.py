@@ -925,13 +925,15 @@ def measure_tolerance_modes(runner, engs, shared, rin, rout, vit, adapter, SPG, 
             out["mllm_fp32"].update({"value_full_pipeline": round(vfull, 4), "ms_per_round_full_pipeline": round(msfull, 1),
                                      "overlap_fallback": fb})
         # gate mode: the same fp32 modules with every fp32-tensor GEMM as three bf16 MFMA products on (hi, lo) operand halves
-        # (`gemm_f32_split`, csrc/ss_gemm.hip SPLIT); decode GEMV on the fp32 weights (HBM-bound: 2 x the bf16 bytes)
+        # (`gemm_f32_split`, csrc/ss_gemm.hip SPLIT) and the 8-slot decode GEMVs through the split-bf16 MFMA form (csrc/ss_gemv.hip
+        # gemv_split_f32_kernel: ONE sweep of the fp32 weights per token, 2 x the bf16 bytes; the decode graph is keyed on the knob)
         _lib.set_tuning("gemm_f32_split", 1)
         try:
             vg, msg = mllm_rate(e32, rin32, rout32, vit32)
             gm = {"ms_per_round_mllm": round(msg, 1), "value_mllm_only": round(vg, 4), "unit": "story-steps/s", "stories": SPG,
-                  "arithmetic": "MLLM half + regressor on fp32 tensors: GEMMs as Ahi*Whi + Ahi*Wlo + Alo*Whi on the bf16 matrix pipe, fp32 "
-                                "accumulate (~1e-5 per GEMM vs the exact chain); GEMV / attention / norms exact fp32; render bf16",
+                  "arithmetic": "MLLM half + regressor on fp32 tensors (fp32 weights, fp32 KV cache): GEMMs AND the lock-step decode GEMVs as "
+                                "Ahi*Whi + Ahi*Wlo + Alo*Whi on the bf16 matrix pipe with fp32 accumulation (4.5e-6 per product vs the fp64 "
+                                "product); attention / norms / RoPE exact fp32; render bf16",
                   "gate": "img_gen_feat <= 1e-3 vs the REAL reference rows at hidden 4096: tests/test_frontend_full_gpu.py::test_gate_mode_*"}
             if adapter is not None:
                 vfull, msfull, fb = full_rate(e32, rin32, rout32, vit32)

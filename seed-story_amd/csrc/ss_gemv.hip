@@ -686,6 +686,212 @@ __global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, 
     tile_body(tile, it, std::false_type{});
 }
 
+// ---- split-bf16 MFMA form for fp32 tensors (the gate mode, tuning knob gemm_f32_split; round 5) ---------------------------------
+// The exact fp32 decode has no MFMA form: 8 lock-step sequences run as TWO 4-sequence sweeps of the dot-product kernels, i.e. the
+// 26.4 GB of fp32 LLaMA weights are streamed twice per token (measured: ~700 of the 1093 ms the gate-mode MLLM half of a round of
+// 8 stories takes).  Here one sweep serves 3..8 sequences through the matrix core with the arithmetic of the split GEMM
+// (ss_gemm.hip SPLIT): w = hi + lo, x = hi + lo in bf16, y += Whi.xhi + Whi.xlo + Wlo.xhi with fp32 accumulation, ~4.5e-6 per
+// product against the exact chain.
+//   * the activations of the launch (<= 8 sequences x <= 4096 k) are split ONCE per workgroup into two bf16 planes in LDS
+//     (wave w stages sequence w, RMSNorm fused: statistic over the whole row in a fixed lane order), sequence stride
+//     2 k + 32 bytes so that the 16 lanes of a ds_read_b128 group (8 sequences x 2 k-chunks) fall on 16 different 16-byte slots;
+//   * a lane streams 32 bytes of fp32 weights per step (row l & 15, k-chunk l >> 4), splits them in registers (8 conversions
+//     + 8 subtractions, far below the HBM time of those bytes) and feeds three MFMAs; two register buffers of 4 steps keep
+//     8-16 KB per wave in flight across tiles; out-of-range steps read a valid address and are zeroed by a select (no branch:
+//     a predicated load would serialise the prefetch);
+//   * K > 4096 (the 11008-deep down projection) runs as K slices in consecutive launches, later slices accumulating onto y;
+//   * persistent workgroups of 8 waves = 8 K ranges of a 16-row tile; partial sums meet in LDS, wave 0 applies the epilogue.
+constexpr int kGsSlice = 4096;
+template <bool SILU>
+__global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, const int kbase, const int kslice, const int ntiles,
+                                                             const int first) {
+    constexpr int CH = 4, NCH = kGvSteps / CH, M = SILU ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    if (gemv_all_done(a)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int K = a.K, N = a.N, nb = a.nb;
+    const int SS = kslice * 2 + 32;                          // bytes between sequences of a plane
+    char* xh = gs_smem;
+    char* xl = gs_smem + 8 * SS;
+    float* part = reinterpret_cast<float*>(gs_smem + 16 * SS);   // [8 waves][M][256]
+    const float* __restrict__ W = (const float*)a.W;
+
+    // ---- stage the activations: wave w <-> sequence w ------------------------------------------------------------------
+    {
+        const int seq = wave;
+        const bool live = seq < nb;
+        const float* xr = (const float*)a.x + (int64_t)(live ? seq : 0) * a.x_ld;
+        float rstd = 1.f;
+        const bool norm = a.norm_w != nullptr;
+        if (norm) {                                          // (only with kbase == 0 && kslice == K: the launcher guarantees it)
+            float ssq = 0.f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq); ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) ssq += __shfl_xor(ssq, off, 64);
+            rstd = 1.0f / sqrtf(ssq / (float)K + a.eps);
+        }
+        for (int k = lane * 4; k < kslice; k += 256) {
+            float4 v = live ? *reinterpret_cast<const float4*>(xr + kbase + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (norm) {
+                const float4 gw = *reinterpret_cast<const float4*>((const float*)a.norm_w + kbase + k);
+                v.x = gw.x * (v.x * rstd); v.y = gw.y * (v.y * rstd); v.z = gw.z * (v.z * rstd); v.w = gw.w * (v.w * rstd);
+            }
+            const uint32_t h01 = f32x2_to_bf16x2_bits(v.x, v.y), h23 = f32x2_to_bf16x2_bits(v.z, v.w);
+            const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+            const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+            *reinterpret_cast<uint2*>(xh + seq * SS + k * 2) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(xl + seq * SS + k * 2) = make_uint2(f32x2_to_bf16x2_bits(r0, r1), f32x2_to_bf16x2_bits(r2, r3));
+        }
+    }
+    __syncthreads();
+
+    const int steps = (kslice + 31) / 32;
+    const int spw = (steps + kGvWaves - 1) / kGvWaves;       // <= 16 (kslice <= 4096)
+    const int s_w0 = wave * spw;                              // this wave's first step
+    // B-fragment base of this lane: sequence i & 7 (columns 8..15 of D duplicate 0..7 and are never stored)
+    const char* bh0 = xh + (i & 7) * SS + q * 16;
+    const char* bl0 = xl + (i & 7) * SS + q * 16;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    uint4 wb[2][M][CH][2];
+    auto row_ptr = [&](int tl, int m) {
+        int row = tl * 16 + i;
+        if (row >= N) row = N - 1;
+        return W + ((int64_t)row + (int64_t)m * N) * K + kbase;
+    };
+    auto load_chunk = [&](auto c_, int tl) {                 // chunk c (4 steps) of row tile tl -> buffer c & 1
+        constexpr int c = decltype(c_)::value;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float* p = row_ptr(tl, m);
+            gv_static_for<CH>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                const int st = s_w0 + c * CH + e;
+                const bool ok = (c * CH + e) < spw && st * 32 + q * 8 < kslice;
+                const float* pp = p + (ok ? st * 32 + q * 8 : 0);   // an invalid step re-reads the slice's first 32 bytes (in range) ...
+                wb[c & 1][m][e][0] = ld16(pp);
+                wb[c & 1][m][e][1] = ld16(pp + 4);
+            });
+        }
+    };
+    auto split8 = [&](const uint4& w0, const uint4& w1, bool ok, uint4& hi, uint4& lo) {
+        const float x0 = __uint_as_float(w0.x), x1 = __uint_as_float(w0.y), x2 = __uint_as_float(w0.z), x3 = __uint_as_float(w0.w);
+        const float x4 = __uint_as_float(w1.x), x5 = __uint_as_float(w1.y), x6 = __uint_as_float(w1.z), x7 = __uint_as_float(w1.w);
+        const uint32_t h0 = f32x2_to_bf16x2_bits(x0, x1), h1 = f32x2_to_bf16x2_bits(x2, x3);
+        const uint32_t h2 = f32x2_to_bf16x2_bits(x4, x5), h3 = f32x2_to_bf16x2_bits(x6, x7);
+        const uint32_t l0 = f32x2_to_bf16x2_bits(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t l1 = f32x2_to_bf16x2_bits(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
+        const uint32_t l2 = f32x2_to_bf16x2_bits(x4 - __uint_as_float(h2 << 16), x5 - __uint_as_float(h2 & 0xffff0000u));
+        const uint32_t l3 = f32x2_to_bf16x2_bits(x6 - __uint_as_float(h3 << 16), x7 - __uint_as_float(h3 & 0xffff0000u));
+        hi = ok ? make_uint4(h0, h1, h2, h3) : make_uint4(0, 0, 0, 0);     // ... and contributes zeros
+        lo = ok ? make_uint4(l0, l1, l2, l3) : make_uint4(0, 0, 0, 0);
+    };
+
+    load_chunk(std::integral_constant<int, 0>{}, tile);
+    for (;;) {
+        const int tnext = tile + (int)gridDim.x;
+        const bool has_next = tnext < ntiles;                 // workgroup-uniform
+        f32x4_t acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        gv_static_for<NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            if constexpr (c + 1 < NCH) load_chunk(std::integral_constant<int, c + 1>{}, tile);
+            else { if (has_next) load_chunk(std::integral_constant<int, 0>{}, tnext); }     // NCH is even: chunk 0 -> buffer 0
+            gv_static_for<CH>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                const int st = s_w0 + c * CH + e;
+                const bool ok = (c * CH + e) < spw && st * 32 + q * 8 < kslice;
+                const int sb = ok ? st * 64 : -q * 16;        // 32 k x 2 bytes per step (invalid: the plane's first 16 bytes)
+                uint4 bh = *reinterpret_cast<const uint4*>(bh0 + sb);
+                uint4 bl = *reinterpret_cast<const uint4*>(bl0 + sb);
+                // (zero operands on BOTH sides: beyond the slice the planes hold whatever the LDS held, and 0 x NaN is NaN)
+                if (!ok) { bh = make_uint4(0, 0, 0, 0); bl = make_uint4(0, 0, 0, 0); }
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    uint4 ah, al;
+                    split8(wb[c & 1][m][e][0], wb[c & 1][m][e][1], ok, ah, al);
+                    acc[m] = gv_mfma<bf16_t>(al, bh, acc[m]);
+                    acc[m] = gv_mfma<bf16_t>(ah, bl, acc[m]);
+                    acc[m] = gv_mfma<bf16_t>(ah, bh, acc[m]);
+                }
+            });
+        });
+        // ---- fold the 8 K ranges and store ----------------------------------------------------------------------------
+        __syncthreads();                                      // the previous tile's fold has finished reading `part`
+#pragma unroll
+        for (int m = 0; m < M; ++m) *reinterpret_cast<f32x4_t*>(part + (wave * M + m) * 256 + lane * 4) = acc[m];
+        __syncthreads();
+        if (wave == 0) {
+            f32x4_t v[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                v[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < kGvWaves; ++w) v[m] += *reinterpret_cast<const f32x4_t*>(part + (w * M + m) * 256 + lane * 4);
+            }
+            const int row0 = tile * 16 + q * 4;               // D[row 4q + r][sequence i]
+            if (i < nb && row0 < N) {
+                float* y = (float*)a.y + (int64_t)i * a.y_ld;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + r < N ? row0 + r : N - 1;
+                    if constexpr (SILU) {
+                        o[r] = silu_g(v[0][r]) * v[M - 1][r];
+                    } else {
+                        float t = v[0][r];
+                        if (first) {
+                            if (a.epi & SS_EPI_BIAS) t += ((const float*)a.bias)[row];
+                            if (a.epi & SS_EPI_RESIDUAL) t += ((const float*)a.residual)[(int64_t)i * a.res_ld + row];
+                        } else {
+                            t += y[row];                      // later K slices accumulate onto the first slice's result
+                        }
+                        o[r] = t;
+                    }
+                }
+                if (row0 + 3 < N && ((a.y_ld | row0) & 3) == 0 && (((size_t)a.y) & 15) == 0) {
+                    *reinterpret_cast<float4*>(y + row0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + r < N) y[row0 + r] = o[r];
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = tnext;
+    }
+}
+
+static int gemv_launch_split_f32(const GemvArgs& a, hipStream_t s) {
+    const bool silu = (a.epi & SS_EPI_SILU_MUL) != 0;
+    const int ntiles = cdiv(a.N, 16);
+    const int cus = tuning_get("gemv_mfma_blocks", 256);
+    const int rounds = cdiv(ntiles, cus);
+    const int blocks = cdiv(ntiles, rounds);
+    int first = 1;
+    for (int kbase = 0; kbase < a.K; kbase += kGsSlice) {
+        const int kslice = a.K - kbase < kGsSlice ? a.K - kbase : kGsSlice;
+        const size_t lds = (size_t)16 * (kslice * 2 + 32) + (size_t)kGvWaves * (silu ? 2 : 1) * 256 * sizeof(float);
+        auto kern = silu ? gemv_split_f32_kernel<true> : gemv_split_f32_kernel<false>;
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[silu ? 1 : 0]) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[silu ? 1 : 0] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a, kbase, kslice, ntiles, first);
+        first = 0;
+    }
+    SS_LAUNCH_CHECK("gemv_split_f32");
+    return SS_OK;
+}
+
 template <typename T>
 static bool gemv_mfma_eligible(const GemvArgs& a) {
     if (a.K <= kGvWaves * kGvSteps * 32) return true;
@@ -797,6 +1003,13 @@ int gemv_launch(const GemvArgs& a0, hipStream_t s) {
     // 24.2 9.9 37.3 21.9 46.2 — one sequence stays with the dot-product kernel, 3 and more go through the matrix core.
     if constexpr (V == 8) {
         if (a.nb >= tuning_get("gemv_mfma_min_nb", 3) && gemv_mfma_eligible<T>(a)) return gemv_launch_mfma<T>(a, s);
+    } else {
+        // fp32 tensors in the gate mode: 3..8 sequences through the split-bf16 MFMA form (one sweep of the weights instead of two
+        // 4-sequence sweeps of the exact dot-product kernels); the RMSNorm prologue needs the whole row in one K slice; SiLU pairs too
+        if (a.nb >= tuning_get("gemv_mfma_min_nb", 3) && a.nb <= 8 && tuning_get("gemm_f32_split", 0) && K % 8 == 0 &&
+            ((!a.norm_w && !(epi & SS_EPI_SILU_MUL)) || K <= kGsSlice) && (((size_t)a.x | (size_t)a.W | (size_t)a.norm_w) & 15) == 0 &&
+            (a.x_ld & 3) == 0)
+            return gemv_launch_split_f32(a, s);
     }
     if (a.nb > 4) {      // no MFMA form for this shape / type: two sweeps of half the sequences each
         const int h1 = a.nb / 2;

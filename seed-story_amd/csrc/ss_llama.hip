@@ -167,6 +167,7 @@ static int prefill_proj(void* splitk_ws, size_t splitk_bytes, const void* A, con
 
 struct SeqGraph {
     int seq0, nb;
+    int mode;                // arithmetic knobs the captured kernels were chosen under (gemm_f32_split): part of the cache key
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
@@ -343,10 +344,11 @@ static int read_state(ss_llama* h, hipStream_t s) {
 
 // captured decode token for slots [seq0, seq0+nb), built on first use
 static int graph_for(ss_llama* h, int seq0, int nb, hipGraphExec_t* out) {
+    const int mode = tuning_get("gemm_f32_split", 0);
     for (const SeqGraph& sg : h->graphs)
-        if (sg.seq0 == seq0 && sg.nb == nb) { *out = sg.exec; return SS_OK; }
+        if (sg.seq0 == seq0 && sg.nb == nb && sg.mode == mode) { *out = sg.exec; return SS_OK; }
     SeqGraph sg;
-    sg.seq0 = seq0; sg.nb = nb; sg.graph = nullptr; sg.exec = nullptr;
+    sg.seq0 = seq0; sg.nb = nb; sg.mode = mode; sg.graph = nullptr; sg.exec = nullptr;
     SS_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = decode_token(h, h->cap_stream, nullptr, seq0, nb);
     hipError_t ce = hipStreamEndCapture(h->cap_stream, &sg.graph);

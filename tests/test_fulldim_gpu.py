@@ -149,6 +149,20 @@ def test_llama_full_width_prefill_continuation_decode(dtype, n_seq):
             assert ours <= 1.5 * theirs + 1e-3, (key, ours, theirs)
 
 
+@pytest.mark.parametrize("n_seq", [4, 8])
+def test_gate_mode_llama_full_width_lockstep_decode(n_seq):
+    """The gate mode (`gemm_f32_split`) at LLaMA-7B width with 4 / 8 lock-step slots: prefill and continuation through the split
+    GEMM, the hipGraph decode through the split-bf16 MFMA form of the GEMV (one sweep of the fp32 weights for all slots; the
+    decode graph is keyed on the knob, so an engine that decoded in exact mode before re-captures) — same oracle, same 1e-4
+    gate as the exact fp32 engine (measured ~1e-5)."""
+    from seedstory import _lib
+    _lib.set_tuning("gemm_f32_split", 1)
+    try:
+        test_llama_full_width_prefill_continuation_decode(torch.float32, n_seq)
+    finally:
+        _lib.set_tuning("gemm_f32_split", 0)
+
+
 _W7B = {}
 
 

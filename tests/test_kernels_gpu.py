@@ -182,6 +182,59 @@ def test_gemv_batched_silu(ops, nb, I, K, dtype):
         assert rel(yb[b], y1) < 6e-3 and rel(yb[b], ref[b]) < 6e-3, b
 
 
+@pytest.mark.parametrize("nb", [3, 5, 8])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 11008), (32066, 4096), (1000, 2816), (100, 256), (37, 4104)])
+def test_gemv_f32_split_gate_mode(ops, nb, N, K):
+    """fp32 decode projections for 3..8 lock-step sequences in the gate mode (`gemm_f32_split`): ONE sweep of the fp32 weights
+    through the split-bf16 MFMA form (csrc/ss_gemv.hip gemv_split_f32_kernel) instead of two 4-sequence sweeps of the exact
+    dot-product kernels.  Against the fp64 product <= 3e-5 (exact kernels <= 3e-6); RMSNorm prologue, bias, residual, ragged N,
+    K slices (11008 = 4096 + 4096 + 2816, 4104 = 4096 + 8) and the SiLU pair."""
+    from seedstory import _lib
+    w = dev(synth.normal_like(74, (N, K), 0.05))
+    x = dev(synth.normal_like(75, (nb, K), 1.0))
+    res = dev(synth.normal_like(76, (nb, N), 1.0))
+    bias = dev(synth.normal_like(73, (N,), 0.5))
+    nw = dev(synth.normal_like(72, (K,), 0.1, 1.0))
+    cases = [{}, {"residual": True}, {"bias": True, "residual": True}]
+    if K <= 4096:
+        cases += [{"norm": True}, {"norm": True, "bias": True, "residual": True}]
+    for kw in cases:
+        r = res if kw.get("residual") else None
+        n = nw if kw.get("norm") else None
+        bs = bias if kw.get("bias") else None
+        exact = ops.gemv_batched(w, x, norm_w=n, eps=1e-5, bias=bs, residual=r)
+        _lib.set_tuning("gemm_f32_split", 1)
+        try:
+            y = ops.gemv_batched(w, x, norm_w=n, eps=1e-5, bias=bs, residual=r)
+        finally:
+            _lib.set_tuning("gemm_f32_split", 0)
+        xr = x.double().cpu()
+        if n is not None:
+            xr = xr * torch.rsqrt((xr * xr).mean(dim=1, keepdim=True) + 1e-5) * nw.double().cpu()
+        ref = xr @ w.double().cpu().t()
+        if bs is not None:
+            ref = ref + bias.double().cpu()
+        if r is not None:
+            ref = ref + res.double().cpu()
+        e_split = float((y.double().cpu() - ref).norm() / ref.norm())
+        e_exact = float((exact.double().cpu() - ref).norm() / ref.norm())
+        assert e_exact < 3e-6 and e_split < 3e-5 and not torch.equal(y, exact), (kw, e_split, e_exact)
+        for b in range(nb):
+            assert float((y[b].double().cpu() - ref[b]).norm() / ref[b].norm()) < 3e-5, (kw, b)
+    if K <= 4096 and N % 2 == 0:
+        I = N // 2
+        _lib.set_tuning("gemm_f32_split", 1)
+        try:
+            ys = ops.gemv_batched(w, x, norm_w=nw, eps=1e-5, silu_mul=True)
+        finally:
+            _lib.set_tuning("gemm_f32_split", 0)
+        xr = x.double().cpu()
+        xr = xr * torch.rsqrt((xr * xr).mean(dim=1, keepdim=True) + 1e-5) * nw.double().cpu()
+        gu = xr @ w.double().cpu().t()
+        refs = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+        assert float((ys.double().cpu() - refs).norm() / refs.norm()) < 5e-5
+
+
 @pytest.mark.parametrize("nb", [1, 3, 4])
 def test_gemv_mfma_form_at_small_batches(ops, nb):
     """The MFMA form is selected from 3 sequences up; by knob it also serves 1 - 4 (same results within rounding), and the
