@@ -699,32 +699,34 @@ __global__ __launch_bounds__(512) void gemv_mfma_exact_kernel(const GemvArgs a, 
 //     + 8 subtractions, far below the HBM time of those bytes) and feeds three MFMAs; two register buffers of 4 steps keep
 //     8-16 KB per wave in flight across tiles; out-of-range steps read a valid address and are zeroed by a select (no branch:
 //     a predicated load would serialise the prefetch);
-//   * K > 4096 (the 11008-deep down projection) runs as K slices in consecutive launches, later slices accumulating onto y;
+//   * K > 4096 (the 11008-deep down projection: N = 4096 = one row tile per workgroup) walks K slices of 4096 INSIDE the tile: the
+//     planes are re-staged per slice (two barriers), the weight stream and the accumulators carry on — one launch, no read-modify-
+//     write of y (the first version ran three launches: 70 us against ~48 for the same bytes);
 //   * persistent workgroups of 8 waves = 8 K ranges of a 16-row tile; partial sums meet in LDS, wave 0 applies the epilogue.
 constexpr int kGsSlice = 4096;
 template <bool SILU>
-__global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, const int kbase, const int kslice, const int ntiles,
-                                                             const int first) {
+__global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, const int ntiles) {
     constexpr int CH = 4, NCH = kGvSteps / CH, M = SILU ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     if (gemv_all_done(a)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int K = a.K, N = a.N, nb = a.nb;
-    const int SS = kslice * 2 + 32;                          // bytes between sequences of a plane
+    const int kmax = K < kGsSlice ? K : kGsSlice;
+    const int SS = kmax * 2 + 32;                            // bytes between sequences of a plane
+    const int nslices = (K + kGsSlice - 1) / kGsSlice;       // K > 4096 (the 11008-deep down projection): slices walked INSIDE the tile
     char* xh = gs_smem;
     char* xl = gs_smem + 8 * SS;
     float* part = reinterpret_cast<float*>(gs_smem + 16 * SS);   // [8 waves][M][256]
     const float* __restrict__ W = (const float*)a.W;
 
-    // ---- stage the activations: wave w <-> sequence w ------------------------------------------------------------------
+    // ---- the activations of K slice [kbase, kbase + kslice) -> the two bf16 planes: wave w <-> sequence w -----------------
+    float rstd = 1.f;
+    const bool norm = a.norm_w != nullptr;                   // (single slice only: the launcher guarantees K <= 4096 with a norm)
     {
-        const int seq = wave;
-        const bool live = seq < nb;
-        const float* xr = (const float*)a.x + (int64_t)(live ? seq : 0) * a.x_ld;
-        float rstd = 1.f;
-        const bool norm = a.norm_w != nullptr;
-        if (norm) {                                          // (only with kbase == 0 && kslice == K: the launcher guarantees it)
+        const bool live = wave < nb;
+        const float* xr = (const float*)a.x + (int64_t)(live ? wave : 0) * a.x_ld;
+        if (norm) {
             float ssq = 0.f;
             for (int k = lane * 4; k < K; k += 256) {
                 const float4 v = *reinterpret_cast<const float4*>(xr + k);
@@ -734,6 +736,11 @@ __global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, c
             for (int off = 1; off < 64; off <<= 1) ssq += __shfl_xor(ssq, off, 64);
             rstd = 1.0f / sqrtf(ssq / (float)K + a.eps);
         }
+    }
+    auto stage = [&](int kbase, int kslice) {
+        const int seq = wave;
+        const bool live = seq < nb;
+        const float* xr = (const float*)a.x + (int64_t)(live ? seq : 0) * a.x_ld;
         for (int k = lane * 4; k < kslice; k += 256) {
             float4 v = live ? *reinterpret_cast<const float4*>(xr + kbase + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (norm) {
@@ -746,29 +753,27 @@ __global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, c
             *reinterpret_cast<uint2*>(xh + seq * SS + k * 2) = make_uint2(h01, h23);
             *reinterpret_cast<uint2*>(xl + seq * SS + k * 2) = make_uint2(f32x2_to_bf16x2_bits(r0, r1), f32x2_to_bf16x2_bits(r2, r3));
         }
-    }
-    __syncthreads();
+    };
 
-    const int steps = (kslice + 31) / 32;
-    const int spw = (steps + kGvWaves - 1) / kGvWaves;       // <= 16 (kslice <= 4096)
-    const int s_w0 = wave * spw;                              // this wave's first step
     // B-fragment base of this lane: sequence i & 7 (columns 8..15 of D duplicate 0..7 and are never stored)
     const char* bh0 = xh + (i & 7) * SS + q * 16;
     const char* bl0 = xl + (i & 7) * SS + q * 16;
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
 
+    // geometry of a slice: steps of 32 k dealt to the 8 waves
+    auto slice_len = [&](int sl) { const int r = K - sl * kGsSlice; return r < kGsSlice ? r : kGsSlice; };
+    auto slice_spw = [&](int kslice) { return ((kslice + 31) / 32 + kGvWaves - 1) / kGvWaves; };   // <= 16
+
     uint4 wb[2][M][CH][2];
-    auto row_ptr = [&](int tl, int m) {
+    auto load_chunk = [&](auto c_, int tl, int sl) {         // chunk c (4 steps) of slice sl of row tile tl -> buffer c & 1
+        constexpr int c = decltype(c_)::value;
+        const int kbase = sl * kGsSlice, kslice = slice_len(sl), spw = slice_spw(kslice), s_w0 = wave * spw;
         int row = tl * 16 + i;
         if (row >= N) row = N - 1;
-        return W + ((int64_t)row + (int64_t)m * N) * K + kbase;
-    };
-    auto load_chunk = [&](auto c_, int tl) {                 // chunk c (4 steps) of row tile tl -> buffer c & 1
-        constexpr int c = decltype(c_)::value;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const float* p = row_ptr(tl, m);
+            const float* p = W + ((int64_t)row + (int64_t)m * N) * K + kbase;
             gv_static_for<CH>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
                 const int st = s_w0 + c * CH + e;
@@ -792,36 +797,53 @@ __global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, c
         lo = ok ? make_uint4(l0, l1, l2, l3) : make_uint4(0, 0, 0, 0);
     };
 
-    load_chunk(std::integral_constant<int, 0>{}, tile);
+    load_chunk(std::integral_constant<int, 0>{}, tile, 0);  // the first weights travel while the activations are staged
+    stage(0, slice_len(0));
+    __syncthreads();
     for (;;) {
         const int tnext = tile + (int)gridDim.x;
         const bool has_next = tnext < ntiles;                 // workgroup-uniform
         f32x4_t acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        gv_static_for<NCH>([&](auto c_) {
-            constexpr int c = decltype(c_)::value;
-            if constexpr (c + 1 < NCH) load_chunk(std::integral_constant<int, c + 1>{}, tile);
-            else { if (has_next) load_chunk(std::integral_constant<int, 0>{}, tnext); }     // NCH is even: chunk 0 -> buffer 0
-            gv_static_for<CH>([&](auto e_) {
-                constexpr int e = decltype(e_)::value;
-                const int st = s_w0 + c * CH + e;
-                const bool ok = (c * CH + e) < spw && st * 32 + q * 8 < kslice;
-                const int sb = ok ? st * 64 : -q * 16;        // 32 k x 2 bytes per step (invalid: the plane's first 16 bytes)
-                uint4 bh = *reinterpret_cast<const uint4*>(bh0 + sb);
-                uint4 bl = *reinterpret_cast<const uint4*>(bl0 + sb);
-                // (zero operands on BOTH sides: beyond the slice the planes hold whatever the LDS held, and 0 x NaN is NaN)
-                if (!ok) { bh = make_uint4(0, 0, 0, 0); bl = make_uint4(0, 0, 0, 0); }
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    uint4 ah, al;
-                    split8(wb[c & 1][m][e][0], wb[c & 1][m][e][1], ok, ah, al);
-                    acc[m] = gv_mfma<bf16_t>(al, bh, acc[m]);
-                    acc[m] = gv_mfma<bf16_t>(ah, bl, acc[m]);
-                    acc[m] = gv_mfma<bf16_t>(ah, bh, acc[m]);
+        for (int sl = 0; sl < nslices; ++sl) {
+            const int kslice = slice_len(sl), spw = slice_spw(kslice), s_w0 = wave * spw;
+            const bool last_slice = sl + 1 == nslices;
+            gv_static_for<NCH>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                if constexpr (c + 1 < NCH) load_chunk(std::integral_constant<int, c + 1>{}, tile, sl);
+                else {                                         // NCH is even: the next slice's / tile's chunk 0 -> buffer 0
+                    if (!last_slice) load_chunk(std::integral_constant<int, 0>{}, tile, sl + 1);
+                    else if (has_next) load_chunk(std::integral_constant<int, 0>{}, tnext, 0);
                 }
+                gv_static_for<CH>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    const int st = s_w0 + c * CH + e;
+                    const bool ok = (c * CH + e) < spw && st * 32 + q * 8 < kslice;
+                    const int sb = ok ? st * 64 : -q * 16;    // 32 k x 2 bytes per step (invalid: the plane's first 16 bytes)
+                    uint4 bh = *reinterpret_cast<const uint4*>(bh0 + sb);
+                    uint4 bl = *reinterpret_cast<const uint4*>(bl0 + sb);
+                    // (zero operands on BOTH sides: beyond the slice the planes hold whatever the LDS held, and 0 x NaN is NaN)
+                    if (!ok) { bh = make_uint4(0, 0, 0, 0); bl = make_uint4(0, 0, 0, 0); }
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        uint4 ah, al;
+                        split8(wb[c & 1][m][e][0], wb[c & 1][m][e][1], ok, ah, al);
+                        acc[m] = gv_mfma<bf16_t>(al, bh, acc[m]);
+                        acc[m] = gv_mfma<bf16_t>(ah, bl, acc[m]);
+                        acc[m] = gv_mfma<bf16_t>(ah, bh, acc[m]);
+                    }
+                });
             });
-        });
+            if (nslices > 1) {                                 // the planes of the next slice (of this tile, or slice 0 of the next tile)
+                const int nsl = last_slice ? 0 : sl + 1;
+                if (!last_slice || has_next) {
+                    __syncthreads();                           // every wave has read its fragments of the current slice
+                    stage(nsl * kGsSlice, slice_len(nsl));
+                    __syncthreads();
+                }
+            }
+        }
         // ---- fold the 8 K ranges and store ----------------------------------------------------------------------------
         __syncthreads();                                      // the previous tile's fold has finished reading `part`
 #pragma unroll
@@ -846,12 +868,8 @@ __global__ __launch_bounds__(512) void gemv_split_f32_kernel(const GemvArgs a, c
                         o[r] = silu_g(v[0][r]) * v[M - 1][r];
                     } else {
                         float t = v[0][r];
-                        if (first) {
-                            if (a.epi & SS_EPI_BIAS) t += ((const float*)a.bias)[row];
-                            if (a.epi & SS_EPI_RESIDUAL) t += ((const float*)a.residual)[(int64_t)i * a.res_ld + row];
-                        } else {
-                            t += y[row];                      // later K slices accumulate onto the first slice's result
-                        }
+                        if (a.epi & SS_EPI_BIAS) t += ((const float*)a.bias)[row];
+                        if (a.epi & SS_EPI_RESIDUAL) t += ((const float*)a.residual)[(int64_t)i * a.res_ld + row];
                         o[r] = t;
                     }
                 }
@@ -875,19 +893,15 @@ static int gemv_launch_split_f32(const GemvArgs& a, hipStream_t s) {
     const int cus = tuning_get("gemv_mfma_blocks", 256);
     const int rounds = cdiv(ntiles, cus);
     const int blocks = cdiv(ntiles, rounds);
-    int first = 1;
-    for (int kbase = 0; kbase < a.K; kbase += kGsSlice) {
-        const int kslice = a.K - kbase < kGsSlice ? a.K - kbase : kGsSlice;
-        const size_t lds = (size_t)16 * (kslice * 2 + 32) + (size_t)kGvWaves * (silu ? 2 : 1) * 256 * sizeof(float);
-        auto kern = silu ? gemv_split_f32_kernel<true> : gemv_split_f32_kernel<false>;
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[silu ? 1 : 0]) {
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set[silu ? 1 : 0] = true;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a, kbase, kslice, ntiles, first);
-        first = 0;
+    const int kmax = a.K < kGsSlice ? a.K : kGsSlice;
+    const size_t lds = (size_t)16 * (kmax * 2 + 32) + (size_t)kGvWaves * (silu ? 2 : 1) * 256 * sizeof(float);
+    auto kern = silu ? gemv_split_f32_kernel<true> : gemv_split_f32_kernel<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[silu ? 1 : 0]) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[silu ? 1 : 0] = true;
     }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a, ntiles);
     SS_LAUNCH_CHECK("gemv_split_f32");
     return SS_OK;
 }

@@ -11,9 +11,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "seed-story_amd"))
-from seedstory import ops  # noqa: E402
+from seedstory import _lib, ops  # noqa: E402
 
-dev, dt = "cuda:0", torch.bfloat16
+dev = "cuda:0"
+dt = torch.float32 if os.environ.get("GEMV_DTYPE") == "f32" else torch.bfloat16
+if dt == torch.float32:      # the gate-mode decode: fp32 weights through the split-bf16 MFMA form
+    _lib.set_tuning("gemm_f32_split", int(os.environ.get("GEMV_SPLIT", "1")))
+ES = 4 if dt == torch.float32 else 2
 NB = int(os.environ.get("GEMV_NB", "8"))
 TOKENS = int(os.environ.get("GEMV_TOKENS", "3"))
 H, I, V, L, COPIES = 4096, 11008, 32066, 32, 4
@@ -38,9 +42,9 @@ for t in range(TOKENS):
         ops.gemv_batched(wo, x, residual=res)
         ops.gemv_batched(wgu, x, norm_w=nw, eps=1e-5, silu_mul=True)
         ops.gemv_batched(wd, xi, residual=res)
-        nbytes += 2 * (wqkv.numel() + wo.numel() + wgu.numel() + wd.numel())
+        nbytes += ES * (wqkv.numel() + wo.numel() + wgu.numel() + wd.numel())
     ops.gemv_batched(heads[t % 2], x)
-    nbytes += 2 * heads[0].numel()
+    nbytes += ES * heads[0].numel()
 torch.cuda.synchronize()
 print(json.dumps({"gemv_pmc": True, "slots_per_sweep": NB, "tokens": TOKENS, "launches": TOKENS * (4 * L + 1),
-                  "algorithmic_bytes_per_launch": round(nbytes / (TOKENS * (4 * L + 1)))}))
+                  "algorithmic_bytes_per_launch": round(nbytes / (TOKENS * (4 * L + 1))), "dtype": str(dt).split(".")[-1]}))
