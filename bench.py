@@ -400,6 +400,9 @@ def cpu_baseline(with_sdxl=True, diffusion_steps=30, budget_s=240.0):
         notes.append("ViT-G not run (budget); < 1 percent of the step")
     return {"value": round(1.0 / step_s, 6), "unit": "story-steps/s", "cores": threads, "kind": "port",
             "seconds_per_story_step": round(step_s, 1),
+            "arithmetic": {"llama": "bf16 (torch CPU)", "unet": "fp32 (bf16 has no fast CPU path), batch 1 x 2 for the CFG pair", "vae": "fp32",
+                           "vit": "fp32", "note": "MIXED: the MLLM leg is priced in bf16, the de-tokenizer legs in fp32 — a baseline for "
+                                                  "orientation, not a like-for-like dtype comparison with the bf16 GPU line"},
             "sample": "full-dimension single measurements composed by the step formula: " + "; ".join(notes) +
                       " (resamplers excluded, < 0.1 %% of the step; wall time of this sample %.0fs)" % (time.perf_counter() - t_start)}
 
