@@ -458,7 +458,19 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
         cfg = (cfg == 21 || cfg == 68) ? 15 : (cfg == 22 || cfg == 29 || cfg == 67 || cfg == 70) ? 10 : 8;
     }
     switch (cfg) {
-        case 1: return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
+        case 1:
+            if constexpr (Tr<T>::kVec == 4) {
+                // split-bf16 gate mode: 256x128 with 8 waves for the big stacked-prefill products (measured, tools/split_bench.py:
+                // [7304, 12288, 4096] 2447 -> 2290 us, [7304, 22016, 4096] 4883 -> 4362 us; N = 4096 equal; the 528-row block is
+                // 40-70 % SLOWER on it, 128x256 never wins) — knob gemm_f32_split_tile: 0 = this rule, 1 / 2 = force 256x128 / 128x256,
+                // 3 = force 128x128
+                if (tuning_get("gemm_f32_split", 0) && g.conv_Cin == 0) {
+                    const int st = tuning_get("gemm_f32_split_tile", 0);
+                    if (st == 1 || (st == 0 && g.M >= 2048 && g.N >= 8192)) return gemm_launch_cfg<T, 256, 128, 4, 2>(g, s);
+                    if (st == 2) return gemm_launch_cfg<T, 128, 256, 2, 4>(g, s);
+                }
+            }
+            return gemm_launch_cfg<T, 128, 128, 2, 2>(g, s);
         case 2: return gemm_launch_cfg<T, 64, 64, 2, 2>(g, s);
         case 8: return gemm_glds_launch_cfg<T, 128, 128, 2, 2, 2>(g, s);   // DMA staging, swizzled, double-buffered
         case 10: return gemm_glds_launch_cfg<T, 64, 64, 2, 2, 2>(g, s);

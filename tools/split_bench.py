@@ -40,6 +40,13 @@ for (M, N, K) in [(7304, 12288, 4096), (7304, 4096, 4096), (7304, 22016, 4096), 
             ref = y
         row["split_us" if split else "exact_us"] = round(us, 1)
         row["split_tflops" if split else "exact_tflops"] = round(2.0 * M * N * K / us / 1e6, 1)
+    for tile in (1, 2):          # A/B: 256x128 / 128x256 with 8 waves instead of 128x128 with 4
+        _lib.set_tuning("gemm_f32_split_tile", tile)
+        us = timed(lambda: ops.gemm(a, w))
+        yt = ops.gemm(a, w)
+        row["split_tile%d_us" % tile] = round(us, 1)
+        row["split_tile%d_rel" % tile] = float((yt - ref).norm() / ref.norm())
+    _lib.set_tuning("gemm_f32_split_tile", 0)
     _lib.set_tuning("gemm_f32_split", 0)
     row["speedup"] = round(row["exact_us"] / row["split_us"], 2)
     row["rel_split_vs_exact"] = float((y - ref).norm() / ref.norm())
