@@ -278,11 +278,12 @@ def test_gemm(ops, M, N, K, dtype):
     assert rel(y, torch.nn.functional.gelu((ref + bias.float()).to(dtype))) < tol * 1.5, "bias+gelu"
 
 
-@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(528, 4096, 4096), (913, 12288, 4096)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(528, 4096, 4096), (913, 12288, 4096), (2304, 8192, 1024), (2100, 8200, 520)])
 def test_gemm_f32_split_bf16_gate_mode(ops, M, N, K):
     """`gemm_f32_split`: fp32 tensors through three bf16 MFMA products on (hi, lo) operand halves with fp32 accumulation
     (csrc/ss_gemm.hip SPLIT).  Against the fp64 product: <= 3e-5 relative (the exact fp32 chain of the same launch: <= 2e-6),
-    i.e. two orders inside the 1e-3 gate it exists for; ragged M / N / K edges and the epilogues behave like the exact kernel."""
+    i.e. two orders inside the 1e-3 gate it exists for; ragged M / N / K edges and the epilogues behave like the exact kernel
+    (the last two shapes take the 256x128 eight-wave tile the dispatch picks for M >= 2048, N >= 8192)."""
     from seedstory import _lib
     a = synth.normal_like(14, (M, K), 1.0)
     w = synth.normal_like(15, (N, K), 0.05)
