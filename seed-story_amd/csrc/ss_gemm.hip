@@ -51,7 +51,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int l15 = lane & 15, grp = lane >> 4;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    // Block -> tile.  Default: x walks N (consecutive workgroups share an A row panel).  SPLIT with g.swz < 0 (knob gemm_f32_split_order):
+    // M-fastest in groups of -g.swz N tiles — consecutive workgroups share a W panel and a band of |swz| W panels stays hot while the
+    // M tiles are walked (the counters put the N-fastest order of [7304, 12288, 4096] at 7.4 x its algorithmic bytes from the fabric)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (SPLIT) {
+        if (g.swz < 0) {
+            const int G = -g.swz, NT = gridDim.x, MT = gridDim.y;
+            const int lin = by * NT + bx;
+            const int band = lin / (G * MT), rem = lin - band * (G * MT);
+            const int gw = (band + 1) * G <= NT ? G : NT - band * G;      // width of this band of N tiles
+            by = rem / gw;
+            bx = band * G + (rem - by * gw);
+        }
+    }
+    const int m_blk = by * BM, n_blk = bx * BN;
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
     const int K = g.K, M = g.M, N = g.N;
@@ -255,6 +269,10 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
             constexpr int SLS = 8 * SKT * V + V;
             const size_t slds = (size_t)(BM + BN) * SLS * sizeof(T);
             auto kern = g.conv_Cin > 0 ? gemm_kernel<T, BM, BN, WM, WN, SKT, true, true> : gemm_kernel<T, BM, BN, WM, WN, SKT, false, true>;
+            GemmArgs g2 = g;
+            // bands of G N tiles walked M-fastest (default 16: [7304, 12288, 4096] 2266 -> 2199 us, [7304, 22016, 4096] 4333 -> 4059 us,
+            // the other MLLM shapes unchanged, profiles/round5_split_gemm_bench.json); 0 = the plain N-fastest grid
+            g2.swz = -tuning_get("gemm_f32_split_order", 16);
             if (slds > 64 * 1024) {
                 static bool attr_set[2] = {false, false};
                 const int which = g.conv_Cin > 0 ? 1 : 0;
@@ -263,7 +281,7 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
                     attr_set[which] = true;
                 }
             }
-            hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), slds, s, g);
+            hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), slds, s, g2);
             SS_LAUNCH_CHECK("gemm_split");
             return SS_OK;
         }

@@ -47,6 +47,13 @@ for (M, N, K) in [(7304, 12288, 4096), (7304, 4096, 4096), (7304, 22016, 4096), 
         row["split_tile%d_us" % tile] = round(us, 1)
         row["split_tile%d_rel" % tile] = float((yt - ref).norm() / ref.norm())
     _lib.set_tuning("gemm_f32_split_tile", 0)
+    for order in (0, 1, 4, 8):       # A/B: the plain N-fastest grid (0) and M-fastest bands of `order` N tiles (default since round 5: 16)
+        _lib.set_tuning("gemm_f32_split_order", order)
+        us = timed(lambda: ops.gemm(a, w))
+        yt = ops.gemm(a, w)
+        row["order%d_us" % order] = round(us, 1)
+        assert float((yt - ref).norm() / ref.norm()) < 1e-4
+    _lib.set_tuning("gemm_f32_split_order", 16)
     _lib.set_tuning("gemm_f32_split", 0)
     row["speedup"] = round(row["exact_us"] / row["split_us"], 2)
     row["rel_split_vs_exact"] = float((y - ref).norm() / ref.norm())
