@@ -68,7 +68,57 @@ SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_
              use_karras_sigmas=False)
 
 
+STANDIN = False      # --standin: exercise this script's own data flow without diffusers (see _standin_build)
+
+
+class _Out:
+    def __init__(self, t):
+        self.sample = t
+        self.prev_sample = t
+
+
+def _standin_build(c_unet, c_vae):
+    """NOT a pin: objects with the call signatures of the diffusers classes used below, backed by oracle/sdxl_modules.py, so that the
+    recipe (weight loading, loop, fixture keys) and tests/test_sdxl_pin.py's consumer can be run end to end in an image without
+    diffusers (tests/test_sdxl_pin.py::test_pin_recipe_runs_end_to_end_with_standin).  The fixture it writes is marked
+    `"diffusers": "STANDIN"` and must never be committed as tests/golden/sdxl_diffusers.*."""
+    import types
+    net = M.UNet2DConditionModel(M.config_from_oracle(c_unet)).eval()
+    net.load_state_dict(S.synth_weights(S.unet_shapes(c_unet), SEEDS["unet"]), strict=True)
+    dec = M.AutoencoderKLDecoder(M.vae_config_from_oracle(c_vae)).eval()
+    dec.load_state_dict(S.synth_weights(S.vae_decoder_shapes(c_vae), SEEDS["vae"]), strict=True)
+
+    class U:
+        def __call__(self, x, t, encoder_hidden_states=None, added_cond_kwargs=None):
+            return _Out(net(x, t, encoder_hidden_states, added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]))
+
+    class V:
+        config = types.SimpleNamespace(scaling_factor=c_vae["scaling_factor"])
+
+        def decode(self, z):
+            return _Out(dec.decode(z))
+
+    class Sch:
+        def set_timesteps(self, n):
+            ts, sig, init = M.euler_tables(n)
+            self.timesteps = torch.tensor(ts, dtype=torch.float32)
+            self.sigmas = torch.tensor(sig, dtype=torch.float32)
+            self.init_noise_sigma = init
+            self._i = {float(t): k for k, t in enumerate(ts)}
+
+        def scale_model_input(self, x, t):
+            s_ = float(self.sigmas[self._i[float(t)]])
+            return x / (s_ * s_ + 1.0) ** 0.5
+
+        def step(self, eps, t, x):
+            k = self._i[float(t)]
+            return _Out(x + eps * (float(self.sigmas[k + 1]) - float(self.sigmas[k])))
+    return U(), V(), Sch()
+
+
 def build(c_unet, c_vae):
+    if STANDIN:
+        return _standin_build(c_unet, c_vae)
     from diffusers import AutoencoderKL, EulerDiscreteScheduler, UNet2DConditionModel
     unet = UNet2DConditionModel.from_config(unet_config(c_unet)).eval()
     unet.load_state_dict(S.synth_weights(S.unet_shapes(c_unet), SEEDS["unet"]), strict=True)
@@ -123,18 +173,30 @@ def run(tag, c_unet, c_vae, hw, tokens, out, full):
     z = synth.normal_like(SEEDS["z"], (1, 4, zhw, zhw), 1.0)
     img = vae.decode(z / vae.config.scaling_factor).sample
     out[tag + ".vae_image"] = img
-    from diffusers.image_processor import VaeImageProcessor
-    u8 = VaeImageProcessor(vae_scale_factor=8).postprocess(img, output_type="np")
+    if STANDIN:
+        u8 = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    else:
+        from diffusers.image_processor import VaeImageProcessor
+        u8 = VaeImageProcessor(vae_scale_factor=8).postprocess(img, output_type="np")
     out[tag + ".vae_u8"] = torch.from_numpy((u8 * 255).round().astype("uint8"))
     return unet, vae, sched
 
 
-def main():
+def main(argv=None):
+    global STANDIN
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the SDXL-base configuration (2.57 B parameters, fp32 on CPU)")
     ap.add_argument("--pipeline", action="store_true", help="also call the real StableDiffusionXLPipeline object (tiny config)")
-    a = ap.parse_args()
-    import diffusers
+    ap.add_argument("--standin", action="store_true", help="self-test of this script without diffusers (NOT a pin; needs --out)")
+    ap.add_argument("--out", default=OUT, help="output path without extension (default: tests/golden/sdxl_diffusers)")
+    a = ap.parse_args(argv)
+    STANDIN = bool(a.standin)
+    if STANDIN:
+        assert a.out != OUT and not a.pipeline, "--standin writes a self-test file: give it its own --out, and no --pipeline"
+        import types
+        diffusers = types.SimpleNamespace(__version__="STANDIN")
+    else:
+        import diffusers
     out = {}
     unet, vae, sched = run("tiny", S.TINY_UNET, S.TINY_VAE, 8, 8, out, False)
     if a.pipeline:
@@ -150,11 +212,11 @@ def main():
     if a.full:
         run("full", S.SDXL_BASE_UNET, S.SDXL_BASE_VAE, 128, 77, out, True)
     from safetensors.torch import save_file
-    save_file({k: v.contiguous() for k, v in out.items()}, OUT + ".safetensors")
-    with open(OUT + ".json", "w") as f:
+    save_file({k: v.contiguous() for k, v in out.items()}, a.out + ".safetensors")
+    with open(a.out + ".json", "w") as f:
         json.dump(dict(diffusers=diffusers.__version__, torch=torch.__version__, seeds=SEEDS, full=a.full,
                        pipeline=a.pipeline, tensors={k: list(v.shape) for k, v in out.items()}), f, indent=1)
-    print("wrote", OUT + ".safetensors", "with", len(out), "tensors; diffusers", diffusers.__version__)
+    print("wrote", a.out + ".safetensors", "with", len(out), "tensors; diffusers", diffusers.__version__)
 
 
 if __name__ == "__main__":

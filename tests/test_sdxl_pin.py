@@ -168,6 +168,27 @@ def _pin(tag, cu, cv, hw, tokens, g, full):
         assert (u8.int() - g[tag + ".vae_u8"].int()).abs().max() <= 1
 
 
+def test_pin_recipe_runs_end_to_end_with_standin(tmp_path):
+    """The recipe that closes the pin cannot run here (no diffusers), but its own data flow can: with `--standin` the script builds
+    its networks from oracle/sdxl_modules.py behind the diffusers call signatures, runs the same loop, and writes a fixture that the
+    SAME consumer below (`_pin`) reads and checks the oracle against.  Proves script + test agree on keys, shapes, seeds and
+    tolerances; it is not a pin (the fixture is marked STANDIN and lives in a temp directory)."""
+    import make_golden_sdxl_diffusers as G
+    from safetensors.torch import load_file
+    out = str(tmp_path / "standin")
+    try:
+        G.main(["--standin", "--out", out])
+    finally:
+        G.STANDIN = False
+    with open(out + ".json") as f:
+        meta = json.load(f)
+    assert meta["diffusers"] == "STANDIN" and not meta["full"]
+    g = load_file(out + ".safetensors")
+    assert set(g) == {"tiny." + k for k in ("unet_eps_t801", "latents_after_2_of_30", "timesteps30", "sigmas30", "init_noise_sigma30",
+                                             "vae_image", "vae_u8")}
+    _pin("tiny", S.TINY_UNET, S.TINY_VAE, 8, 8, g, False)
+
+
 @needs_fixture
 def test_oracle_pinned_on_diffusers_tiny(fixture):
     g, meta = fixture
