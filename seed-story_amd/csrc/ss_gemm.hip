@@ -482,9 +482,9 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
                 // [7304, 12288, 4096] 2447 -> 2290 us, [7304, 22016, 4096] 4883 -> 4362 us; N = 4096 equal; the 528-row block is
                 // 40-70 % SLOWER on it, 128x256 never wins) — knob gemm_f32_split_tile: 0 = this rule, 1 / 2 = force 256x128 / 128x256,
                 // 3 = force 128x128
-                if (tuning_get("gemm_f32_split", 0) && g.conv_Cin == 0) {
+                if (tuning_get("gemm_f32_split", 0)) {
                     const int st = tuning_get("gemm_f32_split_tile", 0);
-                    if (st == 1 || (st == 0 && g.M >= 2048 && g.N >= 8192)) return gemm_launch_cfg<T, 256, 128, 4, 2>(g, s);
+                    if (st == 1 || (st == 0 && g.conv_Cin == 0 && g.M >= 2048 && g.N >= 8192)) return gemm_launch_cfg<T, 256, 128, 4, 2>(g, s);
                     if (st == 2) return gemm_launch_cfg<T, 128, 256, 2, 4>(g, s);
                 }
             }
