@@ -1043,6 +1043,10 @@ def main():
     global STORY_LEN, SINK, CACHE_CAP
     STORY_LEN = 3 if args.mllm_only else args.story_len
     SINK = bool(args.sink)
+    if SINK and ((world > 1 or force_dist) and args.partition == "slots"):
+        raise SystemExit("--sink is a replica-partition mode (the slot ring ships KV rows between ranks with its own eviction rule)")
+    if SINK and args.kv_reuse:
+        raise SystemExit("--sink already implies the 65-row continuation; drop --kv-reuse")
     if SINK:
         CACHE_CAP = (4 + 24 * max(0, STORY_LEN - WINDOW) + 1 + 114 * (WINDOW + 1) + 128 + 127) // 128 * 128
     slots_mode = (world > 1 or force_dist) and args.partition == "slots"
