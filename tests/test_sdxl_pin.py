@@ -189,6 +189,24 @@ def test_pin_recipe_runs_end_to_end_with_standin(tmp_path):
     _pin("tiny", S.TINY_UNET, S.TINY_VAE, 8, 8, g, False)
 
 
+@pytest.mark.skipif(not os.environ.get("SS_TEST_SLOW"), reason="11 minutes of CPU at SDXL-base size: set SS_TEST_SLOW=1")
+def test_pin_recipe_full_size_with_standin(tmp_path):
+    """The `--full` branch of the recipe and of the consumer at SDXL-base size (2.57 B parameters): the module tree of
+    oracle/sdxl_modules.py stands in for diffusers, the oracle's flat program must reproduce its eps rows (batch 2, 128^2 latents),
+    the latents after 2 of 30 Euler + CFG steps, a 256^2 VAE crop and its uint8 image within the pin's own 1e-4 / 1 level.
+    Run once in round 5 in the build container: passed, 6 min (script) + 5 min (consumer) on 8 cores."""
+    import make_golden_sdxl_diffusers as G
+    from safetensors.torch import load_file
+    out = str(tmp_path / "standin_full")
+    try:
+        G.main(["--standin", "--full", "--out", out])
+    finally:
+        G.STANDIN = False
+    g = load_file(out + ".safetensors")
+    assert sum(k.startswith("full.") for k in g) == 7
+    _pin("full", S.SDXL_BASE_UNET, S.SDXL_BASE_VAE, 128, 77, g, True)
+
+
 @needs_fixture
 def test_oracle_pinned_on_diffusers_tiny(fixture):
     g, meta = fixture
