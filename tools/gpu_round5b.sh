@@ -1,9 +1,14 @@
 #!/bin/bash
-# Round 5, second GPU call: the new kernels / modes of this round.   tools/gpu_round5b.sh <stage>
+# Round 5, the later GPU calls: the new kernels / modes of this round.   tools/gpu_round5b.sh <stage>
 #   tests   new + touched tests (split-bf16 gate mode, v3p default, sink at full width, position-table bound, dtype policy)
 #   lnfold  tools/dbg_lnfold_vec.py with the 4-wave folded tiles offered again + the rowpart producers
-#   sink    bench --sink --story-len 25 (BASELINE configs[4] as named), bf16 and --unet-fp8, one whole story each
+#   sink    bench --sink --story-len 25 (BASELINE configs[4] as named), bf16 and --unet-fp8, one whole story each, + the re-prefill comparator
 #   gate    bench defaults without cpu baseline / batch1: tolerance_modes.gate_mode (full pipeline with the split-bf16 MLLM half)
+#   cross   the (unadopted) short-context attention kernel: equality tests + kbench A/B + UNet forward A/B
+#   split   split-bf16 GEMM tests + tools/split_bench.py (exact fp32 chain vs split, tile / order A/B)
+#   traces  rocprofv3 --kernel-trace of the batch-16 UNet forward and of the VAE decode -> tools/trace_summary.py
+#   final   smoke(), the default bench line (every leg), rocprofv3 --kernel-trace --stats of the bench command
+# (counter passes: tools/pmc_round5.sh; the whole suite: tools/gpu_round5.sh tests)
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 case "$1" in
