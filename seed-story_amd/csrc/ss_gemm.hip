@@ -456,7 +456,9 @@ template <> int gemm_sp_dispatch<float>(int, const GemmArgs&, hipStream_t) { ret
 template <> int gemm_sp_dispatch_conv<float>(int, const GemmArgs&, hipStream_t) { return 1; }
 // ping-pong 8-phase 256x256 tiles (ss_gemm_pp.inc): cfg 50-59; same contract (1 = not eligible)
 template <typename T> int gemm_pp_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
+template <typename T> int gemm_pp_dispatch_conv(int cfg, const GemmArgs& g, hipStream_t s);
 template <> int gemm_pp_dispatch<float>(int, const GemmArgs&, hipStream_t) { return 1; }
+template <> int gemm_pp_dispatch_conv<float>(int, const GemmArgs&, hipStream_t) { return 1; }
 // one-stream-per-SIMD kernels (ss_gemm_w4.inc): cfg 90-99; same contract (1 = not eligible)
 template <typename T> int gemm_w4_dispatch(int cfg, const GemmArgs& g, hipStream_t s);
 template <typename T> int gemm_w4_dispatch_conv(int cfg, const GemmArgs& g, hipStream_t s);
@@ -474,7 +476,7 @@ static int gemm_dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
         cfg = g.conv_Cin > 0 ? 69 : 60;
     }
     if (cfg >= 50 && cfg < 60 && Tr<T>::kVec == 8) {   // ping-pong tiles; ineligible shapes (conv, K % 64) take the one-barrier 256x256 tile
-        const int rc = gemm_pp_dispatch<T>(cfg, g, s);
+        const int rc = g.conv_Cin > 0 ? gemm_pp_dispatch_conv<T>(cfg, g, s) : gemm_pp_dispatch<T>(cfg, g, s);
         if (rc <= 0) return rc;
         cfg = g.conv_Cin > 0 ? 69 : 60;
     }
@@ -591,7 +593,7 @@ static size_t tune_rot_bytes(size_t w_bytes) {
     return n * wb;
 }
 
-static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
+static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 56, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
 
 // Candidates are timed in SUSTAINED mode: back-to-back launches over rotating weight copies (every UNet weight is
 // touched once per forward: the copies cycle through more than the 256 MB Infinity Cache when the weight allows it), one
@@ -632,6 +634,10 @@ static int tune_shape(GemmArgs g, void* ws, size_t ws_bytes, size_t a_elems, hip
             for (int z : swzs) {
                 g.swz = z;
                 g.W = w0;
+                if (c >= 50 && c < 60) {   // ping-pong tiles take whole-tile / stride-1 shapes only: time the tile itself, never its fallback
+                    const int rc = g.conv_Cin > 0 ? gemm_pp_dispatch_conv<T>(c, g, s) : gemm_pp_dispatch<T>(c, g, s);
+                    if (rc != SS_OK) break;
+                }
                 if (gemm_dispatch_cfg<T>(c, g, s) != SS_OK) continue;   // warm-up (also faults pages in)
                 g.W = w0 + w_b; gemm_dispatch_cfg<T>(c, g, s);
                 hipEventRecord(e0, s);
