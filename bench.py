@@ -568,7 +568,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         # corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py -> profiles/round2_pmc_summary.json)
         traffic, under_render_us = None, None
         pmcj = {}
-        for name in ("round4_pmc_summary.json", "round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
+        for name in ("round6_pmc_summary.json", "round4_pmc_summary.json", "round3_pmc_summary.json", "round2_pmc_summary.json", "round1_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -791,7 +791,7 @@ def measure_roofline(eng, adapter, SPG, RG, device, dtype, args):
         shipped_cfg = "%d/%d" % tuple(ff1_cfg) if ff1_cfg else None
         traffic_ok = bool(ff1_rec) and ff1_rec.get("cfg_swz") is not None and ff1_rec.get("cfg_swz") == shipped_cfg
         ff1_traffic = ff1_rec.get("hbm_bytes_per_launch") if traffic_ok else None
-        traffic_note = ("HBM-side bytes per launch of the ff1 GEMM from profiles/round4_pmc_summary.json, counters collected on tile cfg/XCD group "
+        traffic_note = ("HBM-side bytes per launch of the ff1 GEMM from profiles/round6_pmc_summary.json (tools/pmc_round6.sh), counters collected on tile cfg/XCD group "
                         "%s = the shipped table's entry for this shape" % shipped_cfg
                         if ff1_traffic else "no PMC record of this shape on the shipped tile (table: %s; record: %s) — traffic withheld"
                         % (shipped_cfg, ff1_rec.get("cfg_swz")))

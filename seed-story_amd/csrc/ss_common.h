@@ -178,6 +178,27 @@ int check_hip(hipError_t e, const char* what);
         int _rc = ::ss::check_hip((expr), #expr);                      \
         if (_rc) return _rc;                                           \
     } while (0)
+// Raise a kernel's dynamic-LDS limit: once per (kernel instantiation, device) — the attribute belongs to the DEVICE's copy of the
+// code object, so a process that drives several devices must set it on each — with the return code checked (a part with
+// less LDS fails here, by name, not later as a generic launch error).  `done` = the call site's static device mask.
+inline int ensure_dyn_lds(const void* kern, size_t bytes, uint64_t& done) {
+    int dev = 0;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done & bit)) {
+        rc = check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (rc) return rc;
+        done |= bit;
+    }
+    return 0;
+}
+#define SS_DYN_LDS(kern, bytes)                                        \
+    do {                                                               \
+        static uint64_t _done = 0;                                     \
+        int _rc = ::ss::ensure_dyn_lds((const void*)(kern), (bytes), _done); \
+        if (_rc) return _rc;                                           \
+    } while (0)
 #define SS_LAUNCH_CHECK(name)                                          \
     do {                                                               \
         int _rc = ::ss::check_hip(hipGetLastError(), name);            \
@@ -202,5 +223,6 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline size_t dtype_size(int dt) { return dt == SS_F32 ? 4 : 2; }
 
 int tuning_get(const char* key, int dflt);
+void tuning_set(const char* key, int value);   // library-side counters readable through ss_get_tuning
 
 }  // namespace ss

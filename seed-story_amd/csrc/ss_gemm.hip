@@ -274,12 +274,8 @@ static int gemm_launch_cfg(const GemmArgs& g, hipStream_t s) {
             // the other MLLM shapes unchanged, profiles/round5_split_gemm_bench.json); 0 = the plain N-fastest grid
             g2.swz = -tuning_get("gemm_f32_split_order", 16);
             if (slds > 64 * 1024) {
-                static bool attr_set[2] = {false, false};
-                const int which = g.conv_Cin > 0 ? 1 : 0;
-                if (!attr_set[which]) {
-                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
-                    attr_set[which] = true;
-                }
+                if (g.conv_Cin > 0) SS_DYN_LDS((gemm_kernel<T, BM, BN, WM, WN, SKT, true, true>), slds);
+                else SS_DYN_LDS((gemm_kernel<T, BM, BN, WM, WN, SKT, false, true>), slds);
             }
             hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), slds, s, g2);
             SS_LAUNCH_CHECK("gemm_split");
@@ -593,7 +589,7 @@ static size_t tune_rot_bytes(size_t w_bytes) {
     return n * wb;
 }
 
-static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 56, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
+static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
 
 // Candidates are timed in SUSTAINED mode: back-to-back launches over rotating weight copies (every UNet weight is
 // touched once per forward: the copies cycle through more than the 256 MB Infinity Cache when the weight allows it), one

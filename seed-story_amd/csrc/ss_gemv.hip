@@ -896,11 +896,9 @@ static int gemv_launch_split_f32(const GemvArgs& a, hipStream_t s) {
     const int kmax = a.K < kGsSlice ? a.K : kGsSlice;
     const size_t lds = (size_t)16 * (kmax * 2 + 32) + (size_t)kGvWaves * (silu ? 2 : 1) * 256 * sizeof(float);
     auto kern = silu ? gemv_split_f32_kernel<true> : gemv_split_f32_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[silu ? 1 : 0]) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[silu ? 1 : 0] = true;
-    }
+    // (the largest request of either instantiation: a full 4096-wide slice, SiLU pair)
+    const size_t lds_max = (size_t)16 * (kGsSlice * 2 + 32) + (size_t)kGvWaves * 2 * 256 * sizeof(float);
+    if (silu) SS_DYN_LDS(gemv_split_f32_kernel<true>, lds_max); else SS_DYN_LDS(gemv_split_f32_kernel<false>, lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a, ntiles);
     SS_LAUNCH_CHECK("gemv_split_f32");
     return SS_OK;
@@ -991,9 +989,8 @@ static int gemv_launch_nb(const GemvArgs& a, int nit, int64_t waves, hipStream_t
         const int64_t max_b = (waves * 2 + threads / 64 - 1) / (threads / 64);   // keep >= ~2 row groups per wave
         if (blocks > max_b) blocks = (int)(max_b < 1 ? 1 : max_b);
     }
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void*)gemv_ldsx_kernel<T, 2, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+    if (lds > 64 * 1024)     // (the request depends on K: set per launch, return code checked)
+        SS_HIP(hipFuncSetAttribute((const void*)gemv_ldsx_kernel<T, 2, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gemv_ldsx_kernel<T, 2, NB>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, s, a);
     SS_LAUNCH_CHECK("gemv_ldsx");
     return SS_OK;
@@ -1024,6 +1021,18 @@ int gemv_launch(const GemvArgs& a0, hipStream_t s) {
             ((!a.norm_w && !(epi & SS_EPI_SILU_MUL)) || K <= kGsSlice) && (((size_t)a.x | (size_t)a.W | (size_t)a.norm_w) & 15) == 0 &&
             (a.x_ld & 3) == 0)
             return gemv_launch_split_f32(a, s);
+        // the gate mode was asked for and this launch cannot take the split form (RMSNorm / SiLU row wider than one 4096 slice,
+        // or 16-byte misalignment): it runs as two EXACT sweeps — correct, slower, and a different arithmetic than the rest of
+        // the run.  Counted (tuning key gemv_split_refused, readable through ss_get_tuning) and reported once.
+        if (a.nb >= tuning_get("gemv_mfma_min_nb", 3) && a.nb <= 8 && tuning_get("gemm_f32_split", 0)) {
+            static bool told = false;
+            tuning_set("gemv_split_refused", tuning_get("gemv_split_refused", 0) + 1);
+            if (!told) {
+                told = true;
+                fprintf(stderr, "[ss] gate mode: GEMV [N=%d, K=%d, %d slots]%s%s runs as exact 4-slot sweeps (split form needs norm / SiLU rows <= %d "
+                                "wide and 16-byte alignment)\n", N, K, a.nb, a.norm_w ? " +RMSNorm" : "", (epi & SS_EPI_SILU_MUL) ? " +SiLU" : "", kGsSlice);
+            }
+        }
     }
     if (a.nb > 4) {      // no MFMA form for this shape / type: two sweeps of half the sequences each
         const int h1 = a.nb / 2;

@@ -39,6 +39,11 @@ int tuning_get(const char* key, int dflt) {
     return it == m.end() ? dflt : it->second;
 }
 
+void tuning_set(const char* key, int value) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_map()[key] = value;
+}
+
 }  // namespace ss
 
 extern "C" {

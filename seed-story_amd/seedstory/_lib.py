@@ -182,8 +182,19 @@ def check(rc, what=""):
         raise SSError("%s failed (%d): %s" % (what or "seedstory call", rc, msg.decode() if msg else "?"))
 
 
+_tuning_gen = 0     # bumped by every set_tuning: captured hipGraphs replay the arithmetic / kernels chosen at capture time
+
+
 def set_tuning(key: str, value: int):
+    global _tuning_gen
     check(lib().ss_set_tuning(key.encode(), int(value)), "ss_set_tuning")
+    _tuning_gen += 1
+
+
+def tuning_generation() -> int:
+    """Counter of ``set_tuning`` calls: part of the key of every captured graph on the Python side (toggling
+    ``gemm_f32_split`` / ``attn_ver`` after a first render used to replay the old arithmetic)."""
+    return _tuning_gen
 
 
 def get_tuning(key: str, default: int = 0) -> int:

@@ -778,7 +778,8 @@ class StableDiffusionXLPipeline:
         # identity = shapes + GENERATION counters of every buffer the captured launches read (conditioning buffers,
         # per-block cross-attention K/V buffers, prepared weights) — never raw addresses or id(): those are reused
         key = (tuple(xin.shape), xin.dtype, tuple(ctx.shape), tuple(cond["time_ids"].flatten().tolist()),
-               getattr(self, "_buf_gen", 0), getattr(self.unet, "_kv_gen", 0), getattr(self.unet, "_prep_gen", 0))
+               getattr(self, "_buf_gen", 0), getattr(self.unet, "_kv_gen", 0), getattr(self.unet, "_prep_gen", 0),
+               _lib.tuning_generation())     # a knob set after the capture (arithmetic mode, kernel version) invalidates it
         for k_old in [k for k in graphs if k[4:] != key[4:]]:      # entries of an older generation are dead
             del graphs[k_old]
         ent = graphs.get(key)

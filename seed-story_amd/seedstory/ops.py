@@ -242,11 +242,13 @@ def gemm_lnfold(x, wg, rstd, shift, colsum, bias_d=None, gelu=False, geglu=False
     return out
 
 
-def rowpart_strips(M, N, K, dtype):
+def rowpart_strips(M, N, K, dtype, epi=0):
     """Number of (sum, sum of squares) partials per row that ``gemm(..., rowpart=)`` writes for this shape (0: not eligible).
     The answer depends on the tile the table holds for the shape, so the shape is tuned FIRST (a first forward on a
-    shape absent from the table used to size the strip buffer from the closed-form tile and then re-tune inside `gemm`)."""
-    tune.ensure_gemm(M, N, K, dt(dtype), 0, None)
+    shape absent from the table used to size the strip buffer from the closed-form tile and then re-tune inside `gemm`) — with
+    the PRODUCER's epilogue flags (`epi`: GELU / GEGLU), because the table key has no epilogue component and the first tune of
+    a shape is the one that sticks."""
+    tune.ensure_gemm(M, N, K, dt(dtype), int(epi), None)
     return int(lib().ss_gemm_rowpart_strips(M, N, K, dt(dtype)))
 
 
