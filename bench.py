@@ -407,6 +407,66 @@ def cpu_baseline(with_sdxl=True, diffusion_steps=30, budget_s=240.0):
                       " (resamplers excluded, < 0.1 %% of the step; wall time of this sample %.0fs)" % (time.perf_counter() - t_start)}
 
 
+def run_config0(seq_len=256):
+    """BASELINE configs[0] as named: "gen_george.py MLLM text-only next-token on CPU, random-init LLaMA-7B config, seq_len=256, 1 image
+    placeholder (plumbing, no GPU)".  The reference's own CPU-runnable case, so it runs the ORACLE (the CPU restatement of the
+    reference, `kind` = "port") — the product path has no CPU fallback by construction.  Full LLaMA-2-7B dimensions (hidden 4096, 32
+    layers, inter 11008, vocab 32066; the 32 layers cycle through 4 distinct random weight sets so nothing is cache-resident), bf16:
+    a 256-token prompt whose 64 <img_i> placeholder rows are replaced by the full-size input resampler's output for one random
+    256 x 4096 ViT feature (gen_george.py:176-188 / models.py:135-150), one prefill, the image-token logits processor, the greedy token."""
+    import seedstory_oracle as O
+    import synth
+    threads = torch.get_num_threads()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(*s):
+        return (torch.randn(*s, generator=g) * 0.02).to(dt)
+
+    t_build = time.perf_counter()
+    sets = [{n: rnd(o, i) for n, (o, i) in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (H, H)), ("self_attn.v_proj", (H, H)),
+                                             ("self_attn.o_proj", (H, H)), ("mlp.gate_proj", (INTER, H)), ("mlp.up_proj", (INTER, H)),
+                                             ("mlp.down_proj", (H, INTER)))} for _ in range(4)]
+    ones = torch.ones(H, dtype=dt)
+    wd = {"model.embed_tokens.weight": rnd(VOCAB, H), "lm_head.weight": rnd(VOCAB, H), "model.norm.weight": ones}
+    for l in range(NL):
+        pfx = "model.layers.%d." % l
+        for n, w in sets[l % 4].items():
+            wd[pfx + n + ".weight"] = w
+        wd[pfx + "input_layernorm.weight"] = ones
+        wd[pfx + "post_attention_layernorm.weight"] = ones
+    rw = synth.resampler_weights(21, "", 8, H, dtype=dt)              # input resampler: 64 queries over the 256-token ViT feature
+    t_build = time.perf_counter() - t_build
+    dims = O.LlamaDims(H, NH, NL, INTER, VOCAB)
+    n_txt = seq_len - 66
+    ids = torch.cat([torch.tensor([BOS]), torch.randint(3, 32000, (n_txt - 1,), generator=g), torch.tensor(IMG_IDS)])   # text, <img> 64 placeholders </img>
+    assert ids.numel() == seq_len
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feat = O.resampler_forward(rw, "", rnd(1, 256, H) * 50.0, 32)                                      # [1, 64, 4096]
+        emb = wd["model.embed_tokens.weight"][ids].clone()
+        emb[n_txt + 1:n_txt + 65] = feat[0]
+        t_embed = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        logits, _, kv = O.llama_forward(wd, dims, emb.unsqueeze(0), torch.arange(seq_len).unsqueeze(0), None, all_logits=False)
+        t_prefill = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sc = O.image_token_logits_processor(int(ids[-1]), logits.reshape(-1, VOCAB)[-1].float(), IMG_IDS)
+        tok = int(sc.argmax())
+        logits2, _, kv = O.llama_forward(wd, dims, wd["model.embed_tokens.weight"][tok].view(1, 1, H), torch.tensor([[seq_len]]), kv, all_logits=False)
+        t_next = time.perf_counter() - t0
+    total = t_embed + t_prefill + t_next
+    return {"metric": "seconds to the next token, CPU plumbing case (BASELINE configs[0])", "value": round(total, 3), "unit": "s", "n_gpus": 0,
+            "steps": 1, "warmup": 0, "ms_per_step": round(total * 1e3, 1), "higher_is_better": False, "scaling": "none", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init LLaMA-2-7B-shaped weights, 4 distinct layer weight sets cycled over 32 layers)",
+            "config": {"workload": "BASELINE configs[0]: text-only prompt of %d tokens with 1 image placeholder (64 rows from the full-size input "
+                                   "resampler), prefill + logits processor + one KV-cached next-token forward, on the host CPU" % seq_len},
+            "cpu_baseline": {"value": round(total, 3), "unit": "s", "cores": threads, "kind": "port",
+                             "sample": "the whole case: input resampler + splice %.2fs, S=%d prefill of 32 layers + lm_head %.2fs, processor + next-token "
+                                       "forward %.2fs (weight build %.1fs not counted)" % (t_embed, seq_len, t_prefill, t_next, t_build)},
+            "first_token": tok, "finite": bool(torch.isfinite(logits2.float()).all())}
+
+
 def flush_c_stdio():
     """RCCL prints its version banner through C stdio when the first communicator comes up; flushed only at exit it would
     land BEHIND the JSON line in a redirected stdout.  Flushing C stdio right after the first collective keeps the JSON
@@ -973,6 +1033,7 @@ def main():
                          "the evicted image's <img> and </img> kept) instead of cutting the prompt and re-prefilling the window; "
                          "use with --story-len 25")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config0", action="store_true", help="BASELINE configs[0]: the CPU plumbing case (S=256, 1 image placeholder, full 7B dims) on the host, no GPU")
     ap.add_argument("--no-roofline", action="store_true", help="flow tests only: skip the roofline section (the JSON line is then not a bench record)")
     ap.add_argument("--no-tolerance-modes", action="store_true",
                     help="skip the extra legs that price the reference-arithmetic modes (fp32 VAE decode, fp32 MLLM half)")
@@ -1014,6 +1075,9 @@ def main():
     if args.max_slots:
         global MAX_SLOTS
         MAX_SLOTS = max(1, min(8, args.max_slots))
+    if args.config0:
+        print(json.dumps(run_config0()))
+        return
     knobs = {}
     for kv in args.knob:
         name, _, val = kv.partition("=")

@@ -118,57 +118,81 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
-// Narrow rows (<= 256 packs, e.g. the UNet's 640/1280-wide tokens): one WAVE per row, 4 rows per block —
-// shuffle reductions only, no LDS, no barriers, every lane busy.
-template <typename T>
+// Narrow rows (<= 256 packs, e.g. the UNet's 640/1280-wide tokens): one WAVE per row — shuffle reductions only, no LDS, no
+// barriers, every lane busy.  Round 6: a wave works on R = 2 rows at once (both rows' loads are in flight before the first
+// reduction starts; same per-row arithmetic and order, bit-identical results): at one row per wave the kernel was a chain of
+// dependent latencies (load -> 12 shuffles -> 12 shuffles -> store) with 2.5 KB in flight per wave, 4.5 TB/s on [16384, 1280].
+template <typename T, int R>
 __global__ __launch_bounds__(256) void layernorm_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const T* __restrict__ b, T* __restrict__ y, int64_t rows,
                                                              int cols, float eps) {
     constexpr int V = Tr<T>::kVec;
     constexpr int MAXP = 4;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int npack = cols / V;
-    const T* xr = x + row * (int64_t)cols;
-    T* yr = y + row * (int64_t)cols;
-    uint4 px[MAXP];
-    float s1 = 0.f;
+    uint4 px[R][MAXP];
+    float s1[R];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int p = lane + i * 64;
-        if (p < npack) {
-            px[i] = ld16(xr + (int64_t)p * V);
-            float f[V];
-            unpack<T>(px[i], f);
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;      // a ragged last wave re-reads the last row (never stored twice)
+        const T* xr = x + row * (int64_t)cols;
 #pragma unroll
-            for (int j = 0; j < V; ++j) s1 += f[j];
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = lane + i * 64;
+            if (p < npack) px[r][i] = ld16(xr + (int64_t)p * V);
         }
     }
-    const float mean = wave_sum(s1) / (float)cols;
-    float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int p = lane + i * 64;
-        if (p < npack) {
-            float f[V];
-            unpack<T>(px[i], f);
+    for (int r = 0; r < R; ++r) {
+        s1[r] = 0.f;
 #pragma unroll
-            for (int j = 0; j < V; ++j) { const float d = f[j] - mean; s2 = fmaf(d, d, s2); }
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = lane + i * 64;
+            if (p < npack) {
+                float f[V];
+                unpack<T>(px[r][i], f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) s1[r] += f[j];
+            }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)cols + eps);
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s1[r]) / (float)cols;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = lane + i * 64;
+            if (p < npack) {
+                float f[V];
+                unpack<T>(px[r][i], f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float d = f[j] - mean[r]; s2 = fmaf(d, d, s2); }
+            }
+        }
+        rstd[r] = 1.0f / sqrtf(wave_sum(s2) / (float)cols + eps);
+    }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int p = lane + i * 64;
         if (p < npack) {
-            float f[V], g[V], h[V];
-            unpack<T>(px[i], f);
+            float g[V], h[V];
             unpack<T>(ld16(w + (int64_t)p * V), g);
             unpack<T>(ld16(b + (int64_t)p * V), h);
 #pragma unroll
-            for (int j = 0; j < V; ++j) f[j] = (f[j] - mean) * rstd * g[j] + h[j];
-            st16(yr + (int64_t)p * V, pack<T>(f));
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    float f[V];
+                    unpack<T>(px[r][i], f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) f[j] = (f[j] - mean[r]) * rstd[r] * g[j] + h[j];
+                    st16(y + (row0 + r) * (int64_t)cols + (int64_t)p * V, pack<T>(f));
+                }
+            }
         }
     }
 }
@@ -180,8 +204,16 @@ int layernorm_launch(const void* x, const void* w, const void* b, void* y, int64
     SS_REQUIRE(cols % V == 0 && cols / V <= kNormMaxPacks * 256, "layernorm: cols=%lld unsupported", (long long)cols);
     if (rows == 0) return SS_OK;
     if (cols / V <= 256 && rows >= 256) {
-        hipLaunchKernelGGL(layernorm_wave_kernel<T>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, (const T*)x,
-                           (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);
+        const int R = rows >= 8192 ? tuning_get("layernorm_rows_per_wave", 2) : 1;      // small launches keep one row per wave (more waves)
+        if (R == 2)
+            hipLaunchKernelGGL((layernorm_wave_kernel<T, 2>), dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, s, (const T*)x,
+                               (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);
+        else if (R == 4)
+            hipLaunchKernelGGL((layernorm_wave_kernel<T, 4>), dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, s, (const T*)x,
+                               (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);
+        else
+            hipLaunchKernelGGL((layernorm_wave_kernel<T, 1>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, (const T*)x,
+                               (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);
         SS_LAUNCH_CHECK("layernorm_wave");
         return SS_OK;
     }
