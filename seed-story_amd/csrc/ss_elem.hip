@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 // Narrow rows (<= 256 packs, e.g. the UNet's 640/1280-wide tokens): one WAVE per row — shuffle reductions only, no LDS, no
-// barriers, every lane busy.  Round 6: a wave works on R = 2 rows at once (both rows' loads are in flight before the first
-// reduction starts; same per-row arithmetic and order, bit-identical results): at one row per wave the kernel was a chain of
-// dependent latencies (load -> 12 shuffles -> 12 shuffles -> store) with 2.5 KB in flight per wave, 4.5 TB/s on [16384, 1280].
+// barriers, every lane busy.  R rows per wave (knob layernorm_rows_per_wave, default 1): round 6 measured R = 2 / 4 (both rows'
+// loads in flight before the first reduction; bit-identical results) and they are SLOWER — [16384, 1280]: 17.4 / 18.4 / 20.6 us for
+// R = 1 / 2 / 4 (4.8 TB/s at R = 1), [65536, 640]: 42.8 / 43.0 / 41.1 (tools/ln_bench.py, profiles/round6_ln_bench.txt): with 32
+// waves per CU the loads of OTHER waves already cover the latency, more rows per wave only lengthen the tail.
 template <typename T, int R>
 __global__ __launch_bounds__(256) void layernorm_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const T* __restrict__ b, T* __restrict__ y, int64_t rows,
@@ -204,7 +205,7 @@ int layernorm_launch(const void* x, const void* w, const void* b, void* y, int64
     SS_REQUIRE(cols % V == 0 && cols / V <= kNormMaxPacks * 256, "layernorm: cols=%lld unsupported", (long long)cols);
     if (rows == 0) return SS_OK;
     if (cols / V <= 256 && rows >= 256) {
-        const int R = rows >= 8192 ? tuning_get("layernorm_rows_per_wave", 2) : 1;      // small launches keep one row per wave (more waves)
+        const int R = rows >= 8192 ? tuning_get("layernorm_rows_per_wave", 1) : 1;
         if (R == 2)
             hipLaunchKernelGGL((layernorm_wave_kernel<T, 2>), dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, s, (const T*)x,
                                (const T*)w, (const T*)b, (T*)y, rows, (int)cols, eps);

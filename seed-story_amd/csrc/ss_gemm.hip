@@ -589,7 +589,7 @@ static size_t tune_rot_bytes(size_t w_bytes) {
     return n * wb;
 }
 
-static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
+static const int kTuneCands[] = {8, 15, 10, 22, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
 
 // Candidates are timed in SUSTAINED mode: back-to-back launches over rotating weight copies (every UNet weight is
 // touched once per forward: the copies cycle through more than the 256 MB Infinity Cache when the weight allows it), one

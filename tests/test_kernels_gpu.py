@@ -318,11 +318,13 @@ def test_gemm_every_tile_config(ops, cfg):
     assert rel(y, a.float() @ w.float().t()) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
+@pytest.mark.parametrize("cfg", [8, 10, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 54, 55, 56, 57, 58,
+                                 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
 @pytest.mark.parametrize("M,N,K", [(200, 300, 512), (1024, 640, 1280), (333, 1000, 64), (4096, 256, 2560), (130, 72, 192)])
 def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
-    """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-23 software-pipelined) on ragged and
-    tile-aligned shapes, with the bias / residual / GELU / GEGLU-pair epilogues."""
+    """Every LDS-DMA tile configuration (8/10/15 double-buffered, 20-46 / 60-72 software-pipelined, 54-58 ping-pong) on ragged and
+    tile-aligned shapes, with the bias / residual / GELU / GEGLU-pair epilogues.  (1024, 640, 1280) is a whole-tile shape of the
+    256x320 ping-pong tiles 56 / 58; on the ragged shapes those two answer "not eligible" and the call takes their fallback tile.)"""
     from seedstory import _lib
     dtype = torch.bfloat16
     a = dev(synth.normal_like(180, (M, K), 1.0, dtype=dtype))
@@ -346,6 +348,31 @@ def test_gemm_dma_tile_configs_with_epilogues(ops, cfg, M, N, K):
         assert rel(y3, full[:, 0::2] * torch.nn.functional.gelu(full[:, 1::2].to(dtype)).float()) < 8e-3
 
 
+@pytest.mark.parametrize("cfg", [54, 55, 56, 57, 58])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 448])
+@pytest.mark.parametrize("M,N", [(512, 640), (520, 330), (256, 320)])
+def test_gemm_pingpong_k_tile_edge_cases(ops, cfg, K, M, N):
+    """The ping-pong tiles (ss_gemm_pp.inc) on 1 .. 7 K tiles: prologue, the odd last tile, the tail forms of the counted vmcnt waits
+    (4-phase schedule 54 / 55 / 56, two-super-phase schedule 57 / 58), whole-tile and ragged shapes; repeated launches must be
+    bit-identical (a mis-counted DMA wait shows up as run-to-run drift) and equal the one-barrier tile 60 bit for bit (same k order)."""
+    from seedstory import _lib
+    dtype = torch.bfloat16
+    a = dev(synth.normal_like(192, (M, K), 1.0, dtype=dtype))
+    w = dev(synth.normal_like(193, (N, K), 0.05, dtype=dtype))
+    bias = dev(synth.normal_like(194, (N,), 0.5, dtype=dtype))
+    res = dev(synth.normal_like(195, (M, N), 1.0, dtype=dtype))
+    try:
+        _lib.set_tuning("gemm_cfg", 60)
+        y60 = ops.gemm(a, w, bias=bias, residual=res)
+        _lib.set_tuning("gemm_cfg", cfg)
+        ys = [ops.gemm(a, w, bias=bias, residual=res) for _ in range(6)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(ys[0], ((a.float() @ w.float().t() + bias.float()).to(dtype) + res).float()) < 4e-3
+    for y in ys:
+        assert torch.equal(y, y60)
+
+
 @pytest.mark.parametrize("cfg", [30, 31, 32, 33, 35, 36, 38, 39, 40, 41, 42, 43, 60, 61, 62, 64])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320])
 def test_gemm_ring_depth_k_tile_edge_cases(ops, cfg, K):
@@ -366,7 +393,7 @@ def test_gemm_ring_depth_k_tile_edge_cases(ops, cfg, K):
         assert torch.equal(y, ys[0])
 
 
-@pytest.mark.parametrize("cfg", [33, 35, 36, 38, 39, 40, 43, 60, 64, 72])
+@pytest.mark.parametrize("cfg", [33, 35, 36, 38, 39, 40, 43, 54, 55, 56, 57, 58, 60, 64, 72])
 @pytest.mark.parametrize("M,N,K", [(8200, 3840, 192), (8192, 10240, 128), (8192, 5120, 64), (16384, 2560, 640)])
 def test_gemm_persistent_multi_tile(ops, cfg, M, N, K):
     """Persistent configurations with several output tiles per workgroup (grid capped at the CU count): the next tile's

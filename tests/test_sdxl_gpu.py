@@ -60,7 +60,37 @@ def test_conv3x3(B, Ci, Co, H, W, stride, up, dtype):
     assert rel(nchw(y2.cpu(), B, Ho, Wo), ref2) < tol * 2
 
 
-@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
+@pytest.mark.parametrize("cfg", [54, 55, 56, 57])
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 64, 320, 16, 16), (1, 128, 640, 32, 8), (4, 320, 256, 8, 32), (1, 64, 320, 16, 16), (3, 192, 320, 16, 16),
+                                         (2, 1280, 640, 16, 16)])
+def test_conv3x3_pingpong_tiles(cfg, B, Ci, Co, H, W):
+    """The ping-pong implicit-GEMM convolution (ss_gemm_pp.inc CONV: cursor staging, zero-page padding through 64-bit lane addresses,
+    constant DMA counts) on whole-tile stride-1 shapes — image borders on every side, pieces that are all padding (top / bottom rows),
+    H != W, 1 .. 20 K tiles per filter tap — plus shapes it must refuse (M % 256 != 0) and hand to its fallback.  Equal to the
+    one-barrier conv tile 69 bit for bit (same k order), repeated launches identical."""
+    from seedstory import _lib, ops
+    from seedstory.diffusion import _conv_w
+    dtype = torch.bfloat16
+    x = synth.normal_like(211, (B, Ci, H, W), 1.0, dtype=dtype)
+    w = synth.normal_like(212, (Co, Ci, 3, 3), 1.0 / math.sqrt(9 * Ci), dtype=dtype)
+    b = synth.normal_like(213, (Co,), 0.5, dtype=dtype)
+    tv = synth.normal_like(214, (B, Co), 0.5, dtype=dtype)
+    res = synth.normal_like(215, (B, Co, H, W), 1.0, dtype=dtype)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + tv.float()[:, :, None, None] + res.float()
+    xd, wd_, bd, tvd, rd = nhwc(x).to(DEV), _conv_w(w).to(DEV), b.to(DEV), tv.to(DEV), nhwc(res).to(DEV)
+    try:
+        _lib.set_tuning("gemm_cfg", 69)
+        y69 = ops.conv3x3(xd, wd_, B, H, W, bias=bd, rowvec=tvd, residual=rd)[0]
+        _lib.set_tuning("gemm_cfg", cfg)
+        ys = [ops.conv3x3(xd, wd_, B, H, W, bias=bd, rowvec=tvd, residual=rd)[0] for _ in range(6)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(nchw(ys[0].cpu(), B, H, W), ref) < 1e-2
+    for y in ys:
+        assert torch.equal(y, y69)
+
+
+@pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 54, 56, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
 def test_conv3x3_dma_tile_configs(cfg, B, Ci, Co, H, W, stride, up):

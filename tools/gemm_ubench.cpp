@@ -61,6 +61,18 @@ int main(int argc, char** argv) {
     tune_fn set_tuning = (tune_fn)dlsym(h, "ss_set_tuning");
     err_fn last_error = (err_fn)dlsym(h, "ss_last_error");
     if (!ss_gemm || !ss_conv || !set_tuning) { fprintf(stderr, "missing symbols\n"); return 2; }
+    if (const char* kn = getenv("UBENCH_KNOB")) {      // "name=int[,name=int...]": extra tuning knobs for the whole run
+        std::string all = kn;
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t e = all.find(',', pos);
+            if (e == std::string::npos) e = all.size();
+            std::string kv = all.substr(pos, e - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+            pos = e + 1;
+        }
+    }
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;

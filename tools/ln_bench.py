@@ -32,4 +32,4 @@ for rows, cols in ((16384, 1280), (65536, 640), (8192, 1280), (16385, 1280), (40
         us = e0.elapsed_time(e1) / 60 * 1e3
         line += "  R=%d %6.1f us (%.2f TB/s)%s" % (R, us, 4.0 * rows * cols / us / 1e6, "" if eq else " NOT-EQUAL")
     print(line, " vs torch fp32 %.1e" % err)
-_lib.set_tuning("layernorm_rows_per_wave", 2)
+_lib.set_tuning("layernorm_rows_per_wave", 1)
