@@ -735,16 +735,21 @@ void flash_attn3_kernel(const AttnArgs a) {
 //   PIPE = false keeps v3's loop (S(t) inside iteration t, tile t+1 still in flight at the barrier, 3 waves per SIMD) and
 //   takes only the address change — the two effects can be measured apart; PIPE = true needs 204 VGPRs (2 waves per SIMD).
 // --------------------------------------------------------------------------------------------
-template <typename T, int HD, bool PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 3)))
+// NW (round 6): waves per workgroup.  4 = 128 query rows per workgroup (3 workgroups per CU); 8 = 256 query rows per workgroup
+// sharing every K / V tile (2 workgroups per CU = 4 waves per SIMD): per-wave arithmetic unchanged (bit-identical results), half
+// the L2 -> LDS traffic per flop — at 4096 tokens x 10 heads x batch 16 the 4-wave form pulls 32 q-blocks x 64 tiles x 16 KB x
+// 160 heads = 5.2 GB per launch through the L2s in 434 us = 12 TB/s, which IS the aggregate L2 rate of the part.
+template <typename T, int HD, bool PIPE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : (NW >= 8 ? 4 : 3))))
 void flash_attn3p_kernel(const AttnArgs a) {
     static_assert(HD == 64, "v3p: head_dim <= 64");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
     constexpr int V = 8;
-    constexpr int BQ2 = 128;             // query rows per block: 4 waves x 32
+    constexpr int BQ2 = 32 * NW;         // query rows per block: NW waves x 32
     constexpr int CPR = HD / V;          // 16-byte chunks per key row
     constexpr int KPI = 64 / CPR;        // keys per DMA instruction
     constexpr int NI = kBKV / KPI;       // DMA instructions per tile per operand
-    constexpr int IPW = NI / 4;          // ... per wave
+    constexpr int IPW = NI / NW > 0 ? NI / NW : 1;   // ... per wave (NW = 16: only the first NI waves stage, one instruction each)
     constexpr int ROWB = HD * 2;         // bytes per key row
     constexpr int TILE_B = kBKV * ROWB;  // bytes of one K (or V) tile
     constexpr int NDB = HD / 16, NKB = kBKV / 16, NKS = HD / 32;
@@ -841,6 +846,7 @@ void flash_attn3p_kernel(const AttnArgs a) {
         vbase_l[i] = vp + (int64_t)key * a.v_ss + lv * V;
     }
     auto issue_tile = [&](int t, int buf) {
+        if constexpr (NW * IPW > NI) { if (wid * IPW >= NI) return; }   // wave-uniform: this wave stages nothing (its vmcnt stays 0)
         const uint32_t kbase = lds0 + (uint32_t)(buf * 2 * TILE_B);
         const uint32_t vbase = kbase + TILE_B;
         const int64_t kadv = (int64_t)t * kBKV * a.k_ss;        // wave-uniform
@@ -1223,14 +1229,34 @@ static int cross_attn64_launch(const AttnArgs& a, int64_t batch, hipStream_t s) 
 template <typename T, bool PIPE>
 static int flash3p_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
     const size_t lds = (size_t)3 * 2 * kBKV * 64 * 2;   // ring of 3 (K, V) tiles
-    const int nqb = cdiv(a.q_len, 128);
+    // 8 / 16 waves per workgroup (256 / 512 query rows share the K / V tiles) once there are enough such workgroups to fill the chip
+    // four times; knob attn_waves: 0 = this rule, 4 / 8 / 16 = force.  Measured (tools/attn_waves_bench.py, profiles/round6_attn_waves.txt,
+    // 4 / 8 / 16 waves): (16, 10 heads, 4096) 839 / 749 / 720 us; (16, 20, 1024) 120 / 112 / 124; (8, 10, 4096) 428 / 380 / 406;
+    // (2, 10, 4096) 119 / 139 / 129 — small launches keep 4 waves.
     const int64_t bh = batch * a.n_heads;
+    const int aw = tuning_get("attn_waves", 0);
+    const bool many = a.ragged || a.kv_len >= 512;     // one- or two-tile contexts (the UNet's cross-attention) gain nothing from sharing tiles
+    const bool w16 = !PIPE && (aw == 16 || (aw == 0 && many && a.q_len >= 2048 && (int64_t)cdiv(a.q_len, 512) * bh >= 1024));
+    const bool w8 = !PIPE && !w16 && (aw == 8 || (aw == 0 && many && a.q_len >= 512 && (int64_t)cdiv(a.q_len, 256) * bh >= 1024));
+    const int nqb = cdiv(a.q_len, w16 ? 512 : w8 ? 256 : 128);
     AttnArgs a2 = a;
     dim3 grid((unsigned)nqb, (unsigned)bh);
     a2.xcd_heads = 0;
     if (bh % 8 == 0 && nqb > 1 && tuning_get("attn_xcd", 1)) {
         a2.xcd_heads = nqb;
         grid = dim3((unsigned)(nqb * bh), 1);
+    }
+    if constexpr (!PIPE) {
+        if (w16) {
+            hipLaunchKernelGGL((flash_attn3p_kernel<T, 64, false, 16>), grid, dim3(1024), lds, s, a2);
+            SS_LAUNCH_CHECK("flash_attn3p");
+            return SS_OK;
+        }
+        if (w8) {
+            hipLaunchKernelGGL((flash_attn3p_kernel<T, 64, false, 8>), grid, dim3(512), lds, s, a2);
+            SS_LAUNCH_CHECK("flash_attn3p");
+            return SS_OK;
+        }
     }
     hipLaunchKernelGGL((flash_attn3p_kernel<T, 64, PIPE>), grid, dim3(256), lds, s, a2);
     SS_LAUNCH_CHECK("flash_attn3p");

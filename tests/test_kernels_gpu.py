@@ -620,3 +620,31 @@ def test_flash_v3p_equals_v3(B, heads, hd, Lq, Lk, causal, dtype):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(outs[6].float()).all())
     assert torch.equal(outs[3], outs[6]), float((outs[3].float() - outs[6].float()).abs().max())
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk,causal", [(16, 10, 4096, 4096, False), (16, 20, 1024, 1024, False), (16, 20, 1024, 64, False), (3, 5, 1000, 1000, False),
+                                                  (2, 3, 130, 77, False), (2, 4, 333, 333, True), (1, 8, 200, 913, True), (1, 2, 33, 4096, True),
+                                                  (2, 4, 700, 700, True), (1, 4, 513, 257, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_flash_v3p_waves_per_workgroup_equal(B, heads, Lq, Lk, causal, dtype):
+    """flash_attn3p with 4 / 8 / 16 waves per workgroup (128 / 256 / 512 query rows sharing the K / V tiles; round 6, knob attn_waves; the
+    default rule picks by launch size): per-wave arithmetic is identical, only the deal of the DMA pieces and the number of waves at the
+    tile barrier change — bit-equal on full and ragged query blocks, one-tile contexts, bottom-right causal."""
+    from seedstory import _lib, ops
+    E = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(Lq * 5 + Lk + heads)
+    q = torch.randn(B, Lq, E, device=DEV, dtype=dtype, generator=g)
+    k = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    v = torch.randn(B, Lk, E, device=DEV, dtype=dtype, generator=g)
+    k[:, Lk // 2] *= 5.0
+    outs = {}
+    try:
+        for w in (4, 8, 16, 0):
+            _lib.set_tuning("attn_waves", w)
+            outs[w] = [ops.attention(q, k, v, heads, None, causal).clone() for _ in range(2)]
+    finally:
+        _lib.set_tuning("attn_waves", 0)
+    assert bool(torch.isfinite(outs[4][0].float()).all())
+    for w in (8, 16, 0):
+        for y in outs[w]:
+            assert torch.equal(y, outs[4][0]), (w, float((y.float() - outs[4][0].float()).abs().max()))

@@ -9,6 +9,9 @@ DEV = "cuda:0"
 dt = torch.bfloat16
 unet = UNet2DConditionModel().to(DEV, dt).init_synthetic(1)
 B = int(os.environ.get("SS_UNET_BATCH", "8"))
+if os.environ.get("SS_ATTN_WAVES"):
+    from seedstory import _lib
+    _lib.set_tuning("attn_waves", int(os.environ["SS_ATTN_WAVES"]))
 if os.environ.get("KB_LNFOLD") is not None:
     unet.enable_lnfold(os.environ["KB_LNFOLD"] != "0")
 x = torch.randn(B, 4, 128, 128, device=DEV, dtype=dt)
