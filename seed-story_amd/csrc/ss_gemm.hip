@@ -56,7 +56,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     // M tiles are walked (the counters put the N-fastest order of [7304, 12288, 4096] at 7.4 x its algorithmic bytes from the fabric)
     int bx = blockIdx.x, by = blockIdx.y;
     if constexpr (SPLIT) {
-        if (g.swz < 0) {
+        if (g.swz <= -1000) {
+            // XCD-aware order (round 6; knob gemm_f32_split_order = 1000 + GM): the dispatcher deals linear workgroup ids round-robin
+            // over the 8 XCDs, so with any id -> tile map that is monotone in the id every XCD's private L2 sees ALL of A and ALL of W
+            // (counters: 10-11 x the algorithmic bytes from the fabric on the stacked-prefill products, bands or not).  xcd_tile_id gives
+            // XCD k a contiguous range of tiles walked in groups of GM m-tiles, as the 16-bit kernels do.
+            int mt_, nt_;
+            xcd_tile_id(-g.swz - 1000, (int)gridDim.y, (int)gridDim.x, (int)(by * gridDim.x + bx), mt_, nt_);
+            by = mt_; bx = nt_;
+        } else if (g.swz < 0) {
             const int G = -g.swz, NT = gridDim.x, MT = gridDim.y;
             const int lin = by * NT + bx;
             const int band = lin / (G * MT), rem = lin - band * (G * MT);
