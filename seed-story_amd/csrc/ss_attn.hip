@@ -1228,7 +1228,10 @@ static int cross_attn64_launch(const AttnArgs& a, int64_t batch, hipStream_t s) 
 
 template <typename T, bool PIPE>
 static int flash3p_launch(const AttnArgs& a, int64_t batch, hipStream_t s) {
-    const size_t lds = (size_t)3 * 2 * kBKV * 64 * 2;   // ring of 3 (K, V) tiles
+    // ring of 3 (K, V) tiles — or as many as the context has: a one-tile context (the UNet's cross-attention, 64 image-feature tokens)
+    // touches ring slot 0 only, and at 16 KB instead of 48 KB per workgroup the CU holds 4 workgroups (register-limited) instead of 3
+    const int64_t kv_tiles = a.ragged ? 3 : cdiv(a.kv_len, kBKV);
+    const size_t lds = (size_t)(kv_tiles < 3 && !PIPE ? (kv_tiles < 1 ? 1 : kv_tiles) : 3) * 2 * kBKV * 64 * 2;
     // 8 / 16 waves per workgroup (256 / 512 query rows share the K / V tiles) once there are enough such workgroups to fill the chip
     // four times; knob attn_waves: 0 = this rule, 4 / 8 / 16 = force.  Measured (tools/attn_waves_bench.py, profiles/round6_attn_waves.txt,
     // 4 / 8 / 16 waves): (16, 10 heads, 4096) 839 / 749 / 720 us; (16, 20, 1024) 120 / 112 / 124; (8, 10, 4096) 428 / 380 / 406;
