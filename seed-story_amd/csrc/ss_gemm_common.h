@@ -210,6 +210,24 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     return (const char*)(size_t)(((uint64_t)hi << 32) | lo);
 }
 
+// the same for data pointers that are DEREFERENCED afterwards: rebuilt from integers a pointer is "flat" to the compiler
+// (flat_load / flat_store: both counters, no scalar-base form), so the result is typed as a global-memory pointer
+typedef __attribute__((address_space(1))) char gmem_char_t;
+typedef __attribute__((address_space(1))) u32x4_t gmem_u32x4_t;
+__device__ __forceinline__ uint4 gmem_ld16(const gmem_char_t* p) {
+    const u32x4_t v = *reinterpret_cast<const gmem_u32x4_t*>(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void gmem_st16(gmem_char_t* p, const uint4& u) {
+    const u32x4_t v = {u.x, u.y, u.z, u.w};
+    *reinterpret_cast<gmem_u32x4_t*>(p) = v;
+}
+__device__ __forceinline__ gmem_char_t* uniform_gptr(const char* p) {
+    const uint64_t v = (uint64_t)(size_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gmem_char_t*)(size_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -542,6 +560,171 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
         };
         if (geglu) readback(std::integral_constant<int, TN / 16>{});
         else readback(std::integral_constant<int, TN / 8>{});
+    }
+}
+
+// Round 6: the same staged epilogue as a SOFTWARE PIPELINE over the 16-row chunks (ping-pong tiles; EM = 0, no row statistics).
+// What the ISA of gemm_epilogue_staged showed on the 256x320 tile (hipcc -S): per chunk ~65 VALU of staging (every value rounded,
+// unpacked and packed AGAIN: round-then-pack is two conversions), then three strictly serial [exec mask -> ds_read_b128 ->
+// lgkmcnt(0) -> two quarter-rate 32-bit multiplies + a 64-bit mad for the row address -> store] pieces, and with a residual
+// three dependent global round trips (load -> vmcnt(0) -> add -> store) — 8 chunks x 3 latency chains per tile with nothing under
+// them: ~5.4 us per tile whether the tile is 128 KB or 160 KB (profiles/round6_gemm_epilogue_cost.txt), i.e. latency, not bytes.
+// Here, per wave:   stage(0) | read(0) | for c: [residual loads(c)] stage(c+1) | wait | add, store(c) | read(c+1)
+//   * a wave's LDS operations execute in order, so stage(c+1) may overwrite the strip right behind read(c)'s ISSUE: the
+//     read-back latency (and the residual's) runs under the next chunk's conversion work, one strip is enough;
+//   * the pieces of a chunk are read / loaded / stored as a batch (no per-piece exec regions: invalid lanes read strip byte 0);
+//   * the row address is (wave-uniform chunk base) + (per-lane byte offset formed once per tile);
+//   * values are converted once (pack of the unrounded sum == pack of the rounded one).
+// Same arithmetic per value, same rounding points as gemm_epilogue_staged: results are bit-identical (ubench equality screen
+// against the direct-epilogue tiles).  WHOLE: the wave's rows are all inside M (the 320-wide and conv tiles take whole tiles only).
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (std::is_same<T, bf16_t>::value) return f32x2_to_bf16x2_bits(a, b);
+    else return f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16);
+}
+template <typename T, int FM, int FN, int EV, bool RES, bool WHOLE>
+__device__ __forceinline__ void gemm_epilogue_staged_pipe(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
+                                                          int lane, char* stg) {
+    static_assert(Tr<T>::kVec == 8, "16-bit outputs only");
+    static_assert(EV >= 1 && EV <= 4, "compile-time variants only");
+    constexpr int TN = FN * 16, RS = TN * 2 + 16;
+    constexpr bool GEGLU = EV == 4;
+    constexpr int LPR = GEGLU ? TN / 16 : TN / 8;      // 16-byte pieces per output row of the strip
+    constexpr int NPC = 16 * LPR;                      // ... per chunk
+    constexpr int NP = (NPC + 63) / 64;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int M = g.M;
+    constexpr bool has_res = RES;                      // the caller dispatches on SS_EPI_RESIDUAL
+    const T* bias = (const T*)g.bias;
+
+    // bias of the lane's 4 columns per fragment: all FN loads in flight together (a test of the flag per fragment put a full
+    // global round trip between any two of them)
+    float bv[FN][4];
+    {
+        uint2 braw[FN];
+        const bool hb = (g.epi & SS_EPI_BIAS) != 0;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) braw[i] = hb ? *reinterpret_cast<const uint2*>(bias + n_base + i * 16 + grp * 4) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            float f[8];
+            unpack<T>(make_uint4(braw[i].x, braw[i].y, 0u, 0u), f);
+            bv[i][0] = f[0]; bv[i][1] = f[1]; bv[i][2] = f[2]; bv[i][3] = f[3];
+        }
+    }
+    // time-embedding vector (EV 3; conv tiles): rows of one 16-row chunk share the batch index (rows_per_batch is a power of
+    // two >= 64 there), kept packed (2 registers per fragment) and re-loaded only when the chunk's batch index changes
+    uint2 rvp[EV == 3 ? FN : 1];
+    int rv_b = -1;
+    auto load_rv = [&](int c) {
+        if constexpr (EV == 3) {
+            const int bidx = (m_base + c * 16) / g.rows_per_batch;      // wave-uniform
+            if (bidx != rv_b) {
+                rv_b = bidx;
+                const T* rp = (const T*)g.rowvec + (int64_t)bidx * g.rowvec_ld + n_base + grp * 4;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) rvp[i] = *reinterpret_cast<const uint2*>(rp + i * 16);
+            }
+        }
+    };
+
+    // per-lane piece coordinates, once per tile
+    uint32_t loff[NP], goff[NP], roff[NP];
+    bool pv[NP];
+    int prow[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int idx = lane + k * 64;
+        const int row = idx / LPR, c16 = idx - row * LPR;
+        pv[k] = (NPC % 64 == 0 || k + 1 < NP) ? true : idx < NPC;
+        prow[k] = row;
+        loff[k] = pv[k] ? (uint32_t)(row * RS + c16 * 16) : 0u;
+        goff[k] = (uint32_t)row * (uint32_t)(g.ldc * 2) + (uint32_t)(c16 * 16);
+        roff[k] = pv[k] ? (uint32_t)row * (uint32_t)(g.ldr * 2) + (uint32_t)(c16 * 16) : 0u;   // lanes without a piece re-read piece 0 (no exec region around the loads)
+    }
+    const int n_out0 = GEGLU ? (n_base >> 1) : n_base;
+    char* Cb = reinterpret_cast<char*>((T*)g.C + (int64_t)m_base * g.ldc + n_out0);                          // wave-uniform
+    const char* Rb = reinterpret_cast<const char*>((const T*)g.residual + (int64_t)m_base * g.ldr + n_base);
+    const int64_t cstep = 32 * g.ldc, rstep = 32 * g.ldr;      // bytes per 16-row chunk
+    char* wrow = stg + l15 * RS + (GEGLU ? grp * 4 : grp * 8);
+
+    auto stage = [&](int c) {
+        load_rv(c);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = acc[i][c][r] + bv[i][r];
+            if constexpr (EV == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = gelu_for<T>(Tr<T>::rnd(t[r]));
+            }
+            if constexpr (EV == 3) {
+                float rv[8];
+                asm volatile("" : "+v"(rvp[i].x), "+v"(rvp[i].y));     // stays packed: unpacked once per chunk, not hoisted into 4 registers per fragment
+                unpack<T>(make_uint4(rvp[i].x, rvp[i].y, 0u, 0u), rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = Tr<T>::rnd(t[r]) + rv[r];
+            }
+            if constexpr (GEGLU) {
+                const float v0 = Tr<T>::rnd(t[0]), v1 = Tr<T>::rnd(t[1]), v2 = Tr<T>::rnd(t[2]), v3 = Tr<T>::rnd(t[3]);
+                const float o0 = v0 * Tr<T>::rnd(gelu_for<T>(v1)), o1 = v2 * Tr<T>::rnd(gelu_for<T>(v3));
+                *reinterpret_cast<uint32_t*>(wrow + i * 16) = pack2<T>(o0, o1);
+            } else {
+                *reinterpret_cast<uint2*>(wrow + i * 32) = make_uint2(pack2<T>(t[0], t[1]), pack2<T>(t[2], t[3]));
+            }
+        }
+    };
+    uint4 u[NP];
+    auto readback = [&]() {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) u[k] = *reinterpret_cast<const uint4*>(stg + loff[k]);
+    };
+
+    // residual pieces: requested RD chunks ahead of their use (12 registers per chunk in flight; the accumulators of the chunks
+    // already staged are free by then)
+    constexpr int RD = 2;
+    uint4 rr[FM][NP];
+    auto row_ok = [&](int c, int k) { return pv[k] && (WHOLE || m_base + c * 16 + prow[k] < M); };
+    auto load_res = [&](int c) {
+        const gmem_char_t* Rc = uniform_gptr(Rb + c * rstep);  // scalar base + 32-bit lane offset (left alone the compiler forms
+                                                               // 64-bit per-lane addresses for the later chunks and spills them)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if constexpr (WHOLE) rr[c][k] = gmem_ld16(Rc + roff[k]);
+            else rr[c][k] = row_ok(c, k) ? gmem_ld16(Rc + roff[k]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    load_rv(0);
+    if (has_res) {
+#pragma unroll
+        for (int c = 0; c < RD && c < FM; ++c) load_res(c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage(0);
+    __builtin_amdgcn_sched_barrier(0);
+    readback();
+#pragma unroll
+    for (int c = 0; c < FM; ++c) {
+        if (has_res && c + RD < FM) load_res(c + RD);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < FM) stage(c + 1);      // behind read(c) in the wave's LDS order; its VALU covers the read-back latency
+        __builtin_amdgcn_sched_barrier(0);
+        gmem_char_t* Cc = uniform_gptr(Cb + c * cstep);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            uint4 o = u[k];
+            if (has_res) {
+                float a[8], b[8];
+                unpack<T>(o, a);
+                unpack<T>(rr[c][k], b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                o = pack<T>(a);
+            }
+            if (row_ok(c, k)) gmem_st16(Cc + goff[k], o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < FM) readback();
     }
 }
 
