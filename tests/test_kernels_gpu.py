@@ -373,6 +373,36 @@ def test_gemm_pingpong_k_tile_edge_cases(ops, cfg, K, M, N):
         assert torch.equal(y, y60)
 
 
+@pytest.mark.parametrize("cfg", [54, 55, 56, 57, 58])
+@pytest.mark.parametrize("M,N,K", [(512, 640, 256), (1000, 512, 320), (256, 320, 64), (2048, 1280, 128)])
+def test_gemm_pingpong_pipelined_epilogue_variants(ops, cfg, M, N, K):
+    """The chunk-pipelined staged epilogue of the ping-pong tiles (gemm_epilogue_staged_pipe: plain, bias, residual with its
+    two-chunk prefetch, bias + residual, GELU, GEGLU pair) against the one-barrier tile 60, which keeps the chunk-serial
+    gemm_epilogue_staged: bit for bit, on whole-tile shapes and on a ragged M (row predicates of the 256-wide tiles; the 320-wide
+    tiles refuse ragged shapes and the call takes their fallback), 1 .. 5 K tiles, repeated launches identical."""
+    from seedstory import _lib
+    dtype = torch.bfloat16
+    a = dev(synth.normal_like(196, (M, K), 1.0, dtype=dtype))
+    w = dev(synth.normal_like(197, (N, K), 0.05, dtype=dtype))
+    bias = dev(synth.normal_like(198, (N,), 0.5, dtype=dtype))
+    res = dev(synth.normal_like(199, (M, N), 1.0, dtype=dtype))
+
+    def run():
+        return [ops.gemm(a, w), ops.gemm(a, w, bias=bias), ops.gemm(a, w, residual=res), ops.gemm(a, w, bias=bias, residual=res),
+                ops.gemm(a, w, bias=bias, gelu=True), ops.gemm_geglu(a, w, bias)]
+    try:
+        _lib.set_tuning("gemm_cfg", 60)
+        ref = run()
+        _lib.set_tuning("gemm_cfg", cfg)
+        outs = [run() for _ in range(3)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    assert rel(ref[3], ((a.float() @ w.float().t() + bias.float()).to(dtype) + res).float()) < 4e-3
+    for o in outs:
+        for y, r in zip(o, ref):
+            assert torch.equal(y, r)
+
+
 @pytest.mark.parametrize("cfg", [30, 31, 32, 33, 35, 36, 38, 39, 40, 41, 42, 43, 60, 61, 62, 64])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320])
 def test_gemm_ring_depth_k_tile_edge_cases(ops, cfg, K):

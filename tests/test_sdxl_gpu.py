@@ -90,6 +90,42 @@ def test_conv3x3_pingpong_tiles(cfg, B, Ci, Co, H, W):
         assert torch.equal(y, y69)
 
 
+@pytest.mark.parametrize("cfg", [54, 55, 56, 57])
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 64, 320, 16, 16), (4, 320, 256, 8, 32), (2, 128, 640, 32, 32), (32, 64, 320, 4, 8)])
+def test_conv3x3_pingpong_pipelined_epilogue_variants(cfg, B, Ci, Co, H, W):
+    """The ResBlock's two convolutions as the ping-pong tiles run them since the pipelined epilogue: conv1 = bias + time-embedding
+    row vector (variant 3: the vector stays packed, re-loaded when a 16-row chunk enters the next image), conv2 = bias + residual
+    (variant 1 with the residual prefetch), plus the plain form — each bit for bit equal to the one-barrier tile 69 (chunk-serial
+    epilogue).  (32, .., 4, 8): 32 pixels per image, so one 128-row wave tile spans four images and the vector changes every other
+    chunk."""
+    from seedstory import _lib, ops
+    from seedstory.diffusion import _conv_w
+    dtype = torch.bfloat16
+    x = synth.normal_like(221, (B, Ci, H, W), 1.0, dtype=dtype)
+    w = synth.normal_like(222, (Co, Ci, 3, 3), 1.0 / math.sqrt(9 * Ci), dtype=dtype)
+    b = synth.normal_like(223, (Co,), 0.5, dtype=dtype)
+    tv = synth.normal_like(224, (B, Co), 0.5, dtype=dtype)
+    res = synth.normal_like(225, (B, Co, H, W), 1.0, dtype=dtype)
+    xd, wd_, bd, tvd, rd = nhwc(x).to(DEV), _conv_w(w).to(DEV), b.to(DEV), tv.to(DEV), nhwc(res).to(DEV)
+
+    def run():
+        return [ops.conv3x3(xd, wd_, B, H, W, bias=bd)[0], ops.conv3x3(xd, wd_, B, H, W, bias=bd, rowvec=tvd)[0],
+                ops.conv3x3(xd, wd_, B, H, W, bias=bd, residual=rd)[0], ops.conv3x3(xd, wd_, B, H, W, rowvec=tvd)[0]]
+    try:
+        _lib.set_tuning("gemm_cfg", 69)
+        ref = run()
+        _lib.set_tuning("gemm_cfg", cfg)
+        outs = [run() for _ in range(3)]
+    finally:
+        _lib.set_tuning("gemm_cfg", 0)
+    conv = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert rel(nchw(ref[1].cpu(), B, H, W), conv + tv.float()[:, :, None, None]) < 1e-2
+    assert rel(nchw(ref[2].cpu(), B, H, W), conv + res.float()) < 1e-2
+    for o in outs:
+        for y, r in zip(o, ref):
+            assert torch.equal(y, r)
+
+
 @pytest.mark.parametrize("cfg", [8, 15, 20, 21, 22, 23, 24, 26, 28, 29, 30, 33, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 54, 56, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72])
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,up", [(2, 64, 96, 16, 16, 1, False), (2, 320, 64, 9, 8, 2, False),
                                                    (1, 128, 200, 6, 5, 1, True), (3, 192, 320, 13, 11, 1, False)])
