@@ -581,6 +581,10 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     if constexpr (std::is_same<T, bf16_t>::value) return f32x2_to_bf16x2_bits(a, b);
     else return f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16);
 }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    if constexpr (std::is_same<T, bf16_t>::value) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+    else { lo = f16_bits_to_f32(w & 0xffffu); hi = f16_bits_to_f32(w >> 16); }
+}
 template <typename T, int FM, int FN, int EV, bool RES, bool WHOLE>
 __device__ __forceinline__ void gemm_epilogue_staged_pipe(const GemmArgs& g, f32x4_t (&acc)[FN][FM], int m_base, int n_base,
                                                           int lane, char* stg) {
@@ -604,6 +608,8 @@ __device__ __forceinline__ void gemm_epilogue_staged_pipe(const GemmArgs& g, f32
         const bool hb = (g.epi & SS_EPI_BIAS) != 0;
 #pragma unroll
         for (int i = 0; i < FN; ++i) braw[i] = hb ? *reinterpret_cast<const uint2*>(bias + n_base + i * 16 + grp * 4) : make_uint2(0u, 0u);
+        // (measured and dropped: the tile's bias segment DMA'd next to the ring by the prologue and read from LDS here — no
+        // difference on any shape, profiles/round6_epilogue_pipe2_ubench.txt: the five loads in flight together were already enough)
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             float f[8];
@@ -666,7 +672,12 @@ __device__ __forceinline__ void gemm_epilogue_staged_pipe(const GemmArgs& g, f32
                 for (int r = 0; r < 4; ++r) t[r] = Tr<T>::rnd(t[r]) + rv[r];
             }
             if constexpr (GEGLU) {
-                const float v0 = Tr<T>::rnd(t[0]), v1 = Tr<T>::rnd(t[1]), v2 = Tr<T>::rnd(t[2]), v3 = Tr<T>::rnd(t[3]);
+                // (value, gate) sit in ADJACENT accumulator registers: rounding them as the pairs they come in and taking the two
+                // gates out of the two packed words leaves the gates in a register pair of the compiler's choice — written as four
+                // separate roundings it gathers (v1, v3) and (v0, v2) into pairs with four v_mov per fragment first
+                float v0, v1, v2, v3;
+                unpack2<T>(pack2<T>(t[0], t[1]), v0, v1);
+                unpack2<T>(pack2<T>(t[2], t[3]), v2, v3);
                 const float o0 = v0 * Tr<T>::rnd(gelu_for<T>(v1)), o1 = v2 * Tr<T>::rnd(gelu_for<T>(v3));
                 *reinterpret_cast<uint32_t*>(wrow + i * 16) = pack2<T>(o0, o1);
             } else {
