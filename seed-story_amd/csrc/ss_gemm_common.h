@@ -569,14 +569,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& g, f32x4_t 
 // lgkmcnt(0) -> two quarter-rate 32-bit multiplies + a 64-bit mad for the row address -> store] pieces, and with a residual
 // three dependent global round trips (load -> vmcnt(0) -> add -> store) — 8 chunks x 3 latency chains per tile with nothing under
 // them: ~5.4 us per tile whether the tile is 128 KB or 160 KB (profiles/round6_gemm_epilogue_cost.txt), i.e. latency, not bytes.
-// Here, per wave:   stage(0) | read(0) | for c: [residual loads(c)] stage(c+1) | wait | add, store(c) | read(c+1)
+// Here, per wave:   [residual loads(0, 1)] stage(0) | read(0) | for c: [residual loads(c+2)] stage(c+1) | wait | add, store(c) | read(c+1)
 //   * a wave's LDS operations execute in order, so stage(c+1) may overwrite the strip right behind read(c)'s ISSUE: the
 //     read-back latency (and the residual's) runs under the next chunk's conversion work, one strip is enough;
 //   * the pieces of a chunk are read / loaded / stored as a batch (no per-piece exec regions: invalid lanes read strip byte 0);
 //   * the row address is (wave-uniform chunk base) + (per-lane byte offset formed once per tile);
 //   * values are converted once (pack of the unrounded sum == pack of the rounded one).
 // Same arithmetic per value, same rounding points as gemm_epilogue_staged: results are bit-identical (ubench equality screen
-// against the direct-epilogue tiles).  WHOLE: the wave's rows are all inside M (the 320-wide and conv tiles take whole tiles only).
+// against the one-barrier tiles, which keep gemm_epilogue_staged).  WHOLE: the wave's rows are all inside M (the 320-wide and conv tiles take whole tiles only).
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
     if constexpr (std::is_same<T, bf16_t>::value) return f32x2_to_bf16x2_bits(a, b);
     else return f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16);
